@@ -1,0 +1,196 @@
+/*
+ * rtamd.h -- C ABI of the MI355X render hot path for raytracer-rs scenes.
+ *
+ * The reference (jameslen/raytracer-rs) is a binary-only Rust crate with no FFI
+ * of its own; every entry point below therefore names the reference code it
+ * stands in for (paths relative to raytracer-rs/src/).  All functions return 0
+ * (RT_OK) or a negative rt_status; none aborts or throws across the boundary.
+ * rt_last_error() gives the text of the last failure on a context.
+ *
+ * Pointers marked "host or device" are probed with hipPointerGetAttributes.
+ * One rt_ctx owns one GPU and one HIP stream and must not be used from two
+ * host threads at once; different contexts are independent.
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,       /* bad argument */
+    RT_ERR_HIP = -2,           /* a HIP runtime call failed */
+    RT_ERR_UNSUPPORTED = -3,   /* scene shape the device path does not handle */
+    RT_ERR_NOT_COMMITTED = -4, /* work call before rt_scene_commit */
+    RT_ERR_NO_DEVICE = -5      /* no usable GPU */
+} rt_status;
+
+/* ---- context ----------------------------------------------------------- */
+int rt_ctx_create(int device, rt_ctx** out);
+void rt_ctx_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
+int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
+/* Upper bound on paths in flight per wavefront batch (default 16Mi). */
+int rt_ctx_set_max_paths(rt_ctx* ctx, uint64_t max_paths);
+int rt_ctx_synchronize(rt_ctx* ctx);
+
+/* ---- scene description --------------------------------------------------
+ * Replaces the object graph of Arc<dyn Hittable>/Arc<dyn Material>/Arc<dyn Texture>
+ * (shapes.rs:14-17, materials.rs:13-18, texture.rs:10-12) by flat arrays.
+ * Every primitive carries
+ *   id    : its position in a depth-first walk of the scene in insertion order
+ *           (Scene.shapes order, Box2 sides in shapes.rs:459-466 order); reported by
+ *           rt_intersect_batch and used to break exact t ties (higher id wins, the
+ *           "later shape wins" rule of scene.rs:32-38);
+ *   group : 0 = top level world, g > 0 = member of groups[g-1].
+ * A group is what TransformedObject<T> (shapes.rs:26-97) or ConstantMedium<T>
+ * (shapes.rs:624-705) wraps. */
+typedef enum rt_material_kind {
+    RT_MAT_LAMBERTIAN = 0,    /* materials.rs:45-61  : tex */
+    RT_MAT_METAL = 1,         /* materials.rs:84-95  : albedo, fuzz (caller clamps to <=1 as MetalMat::new does) */
+    RT_MAT_DIELECTRIC = 2,    /* materials.rs:117-148: ior */
+    RT_MAT_DIFFUSE_LIGHT = 3, /* materials.rs:176-184: tex */
+    RT_MAT_ISOTROPIC = 4      /* materials.rs:204-215: tex */
+} rt_material_kind;
+
+typedef struct rt_material {
+    uint32_t kind;
+    uint32_t tex;
+    float albedo[3];
+    float fuzz;
+    float ior;
+    uint32_t reserved;
+} rt_material;
+
+typedef enum rt_texture_kind {
+    RT_TEX_SOLID = 0,   /* texture.rs:18-22 : color */
+    RT_TEX_CHECKER = 1, /* texture.rs:52-62 : odd, even = texture indices */
+    RT_TEX_NOISE = 2,   /* texture.rs:78-82 : freq, table = perlin table id */
+    RT_TEX_IMAGE = 3    /* texture.rs:96-117: table = image id */
+} rt_texture_kind;
+
+typedef struct rt_texture {
+    uint32_t kind;
+    float color[3];
+    uint32_t odd, even;
+    float freq;
+    uint32_t table;
+} rt_texture;
+
+typedef enum rt_group_kind { RT_GROUP_INSTANCE = 1, RT_GROUP_MEDIUM = 2 } rt_group_kind;
+
+typedef struct rt_group {
+    uint32_t kind;           /* rt_group_kind */
+    uint32_t has_xform;      /* 0: members are in world space */
+    float m[12];             /* object->world, 3 rows x 4 columns (row major) */
+    float minv[12];          /* world->object */
+    double neg_inv_density;  /* media: -1/density in f64 (shapes.rs:642) */
+    uint32_t mat;            /* media: the Isotropic phase material */
+    uint32_t reserved;
+} rt_group;
+
+int rt_scene_clear(rt_ctx* ctx);
+/* Sphere / MovingSphere (shapes.rs:99-250).  c0_r: n x (cx,cy,cz,r).  c1: n x 3 and t01: n x (t0,t1)
+ * and moving: n flags may be NULL when nothing moves. */
+int rt_scene_set_spheres(rt_ctx* ctx, uint32_t n, const float* c0_r, const float* c1, const float* t01,
+                         const uint8_t* moving, const uint32_t* mat, const uint32_t* id, const uint32_t* group);
+/* XYRect / XZRect / YZRect (shapes.rs:252-442).  axis: 0 = XY (z = k), 1 = XZ (y = k), 2 = YZ (x = k);
+ * bounds: n x (min.x, min.y, max.x, max.y) exactly as the Rust constructors take them. */
+int rt_scene_set_rects(rt_ctx* ctx, uint32_t n, const uint8_t* axis, const float* k, const float* bounds,
+                       const uint32_t* mat, const uint32_t* id, const uint32_t* group);
+int rt_scene_set_groups(rt_ctx* ctx, uint32_t n, const rt_group* groups);
+int rt_scene_set_materials(rt_ctx* ctx, uint32_t n, const rt_material* mats);
+int rt_scene_set_textures(rt_ctx* ctx, uint32_t n, const rt_texture* texs);
+/* Perlin tables (perlin.rs:12-44): vec = 256 x 3 gradients, perm = perm_x|perm_y|perm_z, 3 x 256. */
+int rt_scene_set_perlin(rt_ctx* ctx, uint32_t table, const float* vec, const int32_t* perm);
+/* Decoded RGB8 image, row 0 = top (texture.rs:84-93). */
+int rt_scene_set_image(rt_ctx* ctx, uint32_t table, uint32_t w, uint32_t h, const uint8_t* rgb);
+/* Stands in for BVHNode::from_scene(&world, t0, t1) (bvh_node.rs:48-120, main.rs:458): builds the
+ * linear two-level BVH on the host and uploads everything. */
+int rt_scene_commit(rt_ctx* ctx, float shutter_t0, float shutter_t1);
+
+typedef struct rt_scene_info {
+    uint64_t n_prims, n_nodes, n_groups, n_media;
+    uint32_t max_depth;    /* deepest stack the traversal can need */
+    uint32_t stack_entries; /* entries per lane the kernels were specialised for */
+    uint64_t device_bytes;
+    double build_seconds;
+} rt_scene_info;
+int rt_scene_get_info(rt_ctx* ctx, rt_scene_info* out);
+
+/* ---- camera (camera.rs:14-25; built by Camera::new, camera.rs:28-52) ------ */
+typedef struct rt_camera {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius;
+    float time_start, time_end;
+} rt_camera;
+
+/* ---- hit() path on a ray batch -------------------------------------------
+ * world.intersect(ray, tmin, tmax) (bvh_node.rs:145-164 / scene.rs:27-41) for n rays given as
+ * seven arrays.  Outputs (each may be NULL): prim (>= 0 primitive id, -1 miss, <= -2 medium
+ * -(k+2) for the k-th medium group), inst (index of the instance group hit, else -1), t,
+ * normal (n x 3, face-set as hit_record.rs:32-42), front, uv (n x 2), point (n x 3).
+ * Media take their free-flight sample from RNG stream (seed, pixel = ray index, sample 0), bounce 0.
+ * All pointers: host or device (all of one kind). */
+int rt_intersect_batch(rt_ctx* ctx, uint64_t n, const float* ox, const float* oy, const float* oz,
+                       const float* dx, const float* dy, const float* dz, const float* time, float tmin,
+                       float tmax, uint32_t seed, int32_t* prim, int32_t* inst, float* t, float* normal,
+                       uint8_t* front, float* uv, float* point);
+
+/* ---- render loop ------------------------------------------------------------
+ * The pixel/sample loop of main.rs:463-482 over ray_color (main.rs:44-63) as a wavefront
+ * path tracer.  Adds samples [sample0, sample1) of every pixel this rank owns to
+ * accum_rgb (height x width x 3 floats, row 0 = top; host or device), one sample at a
+ * time in sample order, so that splitting a render by samples or by ranks changes no bit.
+ * Ownership: tile_size x tile_size tiles dealt round-robin, tile index % nranks == rank. */
+typedef struct rt_render_params {
+    uint32_t width, height;
+    uint32_t sample0, sample1;
+    uint32_t max_depth; /* 50 in every reference preset */
+    float background[3];
+    uint32_t seed;
+    uint32_t tile_size; /* 0 -> 32 */
+    uint32_t rank, nranks; /* nranks 0 -> 1 */
+    uint32_t reserved;
+} rt_render_params;
+
+typedef struct rt_render_stats {
+    uint64_t rays;        /* world.intersect calls issued by ray_color (primary + scattered) */
+    uint64_t paths;       /* camera samples */
+    uint32_t batches;
+    uint32_t bounce_launches;
+    double render_ms;     /* wall time inside rt_render, device-synchronised */
+    double trace_ms, shade_ms, raygen_ms, accumulate_ms; /* HIP-event kernel time when profiling is on */
+    uint64_t trace_launches, shade_launches;
+} rt_render_stats;
+
+int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* accum_rgb,
+              rt_render_stats* stats);
+/* Time every kernel launch with HIP events on the context's stream (costs a little; off by default). */
+int rt_profile_enable(rt_ctx* ctx, int on);
+
+/* vec3_to_rgb(color * inv_samples) (main.rs:307-313,460,481): out[i] = (256*clamp(sum[i]/spp,0,0.999)) as u8.
+ * sum_rgb and out: host or device. */
+int rt_resolve_u8(rt_ctx* ctx, const float* sum_rgb, uint64_t n_pixels, uint32_t spp, uint8_t* out);
+
+/* Pixels owned by `rank` under the tile deal of rt_render, in render order (tile-major). Writes up to
+ * cap pixel indices (y*width+x) to out (host) and returns the count in *n. */
+int rt_owned_pixels(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t rank, uint32_t nranks,
+                    uint32_t* out, uint64_t cap, uint64_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

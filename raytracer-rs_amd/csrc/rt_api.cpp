@@ -1,0 +1,911 @@
+// C ABI of the MI355X render path: context, scene upload, BVH commit, ray-batch and render drivers.
+// Compiled with hipcc; there is no CPU fallback: every work call needs a GPU and fails with
+// RT_ERR_NO_DEVICE / RT_ERR_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rtamd.h"
+#include "rt_bvh.h"
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct HostSpheres {
+    std::vector<float> c0r, c1, t01;
+    std::vector<uint8_t> moving;
+    std::vector<uint32_t> mat, id, group;
+    uint32_t n = 0;
+};
+struct HostRects {
+    std::vector<uint8_t> axis;
+    std::vector<float> k, bounds;
+    std::vector<uint32_t> mat, id, group;
+    uint32_t n = 0;
+};
+struct HostImage {
+    uint32_t w = 0, h = 0;
+    std::vector<uint8_t> rgb;
+};
+
+enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_COUNT = 4 };
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // host-side scene description
+    HostSpheres sph;
+    HostRects rect;
+    std::vector<rt_group> groups;
+    std::vector<rt_material> mats;
+    std::vector<rt_texture> texs;
+    std::map<uint32_t, std::vector<float>> perlin_vec;
+    std::map<uint32_t, std::vector<int32_t>> perlin_perm;
+    std::map<uint32_t, HostImage> images;
+
+    // device scene
+    bool committed = false;
+    DevBuf d_prims, d_moving, d_nodes, d_groups, d_mats, d_texs, d_perlin, d_images;
+    std::vector<DevBuf> d_image_data;
+    rtd::Scene scene{};
+    int stack_entries = 16;
+    bool has_groups = false;
+    rt_scene_info info{};
+
+    // wavefront buffers
+    uint64_t max_paths = 16ull << 20;
+    uint64_t capacity = 0;
+    DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
+    uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
+    uint64_t n_owned = 0;
+    uint32_t* h_counts = nullptr;  // pinned: counts[2], overflow
+    unsigned long long* h_rays = nullptr;
+
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, std::pair<int, int>>> ev_used;  // slot, (start idx, stop idx)
+    size_t ev_next = 0;
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int hip_fail(rt_ctx* c, hipError_t e, const char* what) {
+    (void)hipGetLastError();
+    return fail(c, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+int ensure(rt_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return RT_OK;
+    b.release();
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return RT_OK;
+}
+int upload(rt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// ---- flattening of the host description into device records -------------------------
+struct PrimSrc {
+    bool sphere;
+    uint32_t idx;
+};
+
+void sphere_box(const rt_ctx* c, uint32_t i, float t0, float t1, float lo[3], float hi[3]) {
+    const float* a = &c->sph.c0r[4 * (size_t)i];
+    float r = std::fabs(a[3]);
+    for (int k = 0; k < 3; k++) {
+        lo[k] = a[k] - r;
+        hi[k] = a[k] + r;
+    }
+    if (!c->sph.moving.empty() && c->sph.moving[i]) {
+        // MovingSphere::bounding_box(t0,t1) (shapes.rs:236-249): union of the boxes at both shutter ends
+        const float* c1 = &c->sph.c1[3 * (size_t)i];
+        float s0 = c->sph.t01[2 * (size_t)i], s1 = c->sph.t01[2 * (size_t)i + 1];
+        for (int e = 0; e < 2; e++) {
+            float tt = e ? t1 : t0;
+            float f = (tt - s0) / (s1 - s0);
+            for (int k = 0; k < 3; k++) {
+                float ck = a[k] + f * (c1[k] - a[k]);
+                lo[k] = e ? std::min(lo[k], ck - r) : ck - r;
+                hi[k] = e ? std::max(hi[k], ck + r) : ck + r;
+            }
+        }
+    }
+}
+void rect_box(const rt_ctx* c, uint32_t i, float lo[3], float hi[3]) {
+    // bounding_box of XY/XZ/YZRect (shapes.rs:308-313,372-377,436-441): +-1e-4 on the thin axis
+    const float* b = &c->rect.bounds[4 * (size_t)i];
+    float k = c->rect.k[i];
+    int ax = c->rect.axis[i] == 0 ? 2 : (c->rect.axis[i] == 1 ? 1 : 0);
+    int a0 = ax == 0 ? 1 : 0, a1 = ax == 2 ? 1 : 2;
+    lo[ax] = k - 0.0001f;
+    hi[ax] = k + 0.0001f;
+    lo[a0] = std::min(b[0], b[2]);
+    hi[a0] = std::max(b[0], b[2]);
+    lo[a1] = std::min(b[1], b[3]);
+    hi[a1] = std::max(b[1], b[3]);
+}
+// Boxes only cull; widen them a little so that rounding in the primitive tests (which follow the
+// reference's arithmetic exactly) can never place an accepted hit outside its leaf box.
+void widen(float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; k++) {
+        float m = std::max(std::max(std::fabs(lo[k]), std::fabs(hi[k])), hi[k] - lo[k]);
+        float pad = 2e-6f * m + 1e-30f;
+        lo[k] -= pad;
+        hi[k] += pad;
+    }
+}
+void xform_box(const float* m, const float lo[3], const float hi[3], float olo[3], float ohi[3]) {
+    for (int k = 0; k < 3; k++) {
+        olo[k] = INFINITY;
+        ohi[k] = -INFINITY;
+    }
+    for (int corner = 0; corner < 8; corner++) {
+        float p[3] = {(corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]};
+        for (int r = 0; r < 3; r++) {
+            float v = m[4 * r] * p[0] + m[4 * r + 1] * p[1] + m[4 * r + 2] * p[2] + m[4 * r + 3];
+            olo[r] = std::min(olo[r], v);
+            ohi[r] = std::max(ohi[r], v);
+        }
+    }
+}
+
+rtd::Prim make_prim(const rt_ctx* c, const PrimSrc& s, std::vector<rtd::Moving>& moving) {
+    rtd::Prim p{};
+    if (s.sphere) {
+        const float* a = &c->sph.c0r[4 * (size_t)s.idx];
+        for (int k = 0; k < 4; k++) p.a[k] = a[k];
+        bool mv = !c->sph.moving.empty() && c->sph.moving[s.idx];
+        p.info = (mv ? rtd::PK_MOVING_SPHERE : rtd::PK_SPHERE) | (c->sph.mat[s.idx] << 8);
+        p.id = c->sph.id[s.idx];
+        if (mv) {
+            rtd::Moving m{};
+            for (int k = 0; k < 3; k++) m.c1[k] = c->sph.c1[3 * (size_t)s.idx + k];
+            m.t0 = c->sph.t01[2 * (size_t)s.idx];
+            m.t1 = c->sph.t01[2 * (size_t)s.idx + 1];
+            p.aux = (uint32_t)moving.size();
+            moving.push_back(m);
+        }
+    } else {
+        const float* b = &c->rect.bounds[4 * (size_t)s.idx];
+        p.a[0] = c->rect.k[s.idx];
+        p.a[1] = b[0];  // min0
+        p.a[2] = b[1];  // min1
+        p.a[3] = b[2];  // max0
+        p.b0 = b[3];    // max1
+        uint32_t kind = c->rect.axis[s.idx] == 0 ? rtd::PK_RECT_XY : (c->rect.axis[s.idx] == 1 ? rtd::PK_RECT_XZ : rtd::PK_RECT_YZ);
+        p.info = kind | (c->rect.mat[s.idx] << 8);
+        p.id = c->rect.id[s.idx];
+    }
+    return p;
+}
+
+uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return (uint32_t)strtoul(v, nullptr, 10);
+}
+
+int alloc_wavefront(rt_ctx* c, uint64_t cap) {
+    if (c->capacity >= cap) return RT_OK;
+    int rc;
+    for (int s = 0; s < 2; s++) {
+        for (int a = 0; a < 3; a++)
+            if ((rc = ensure(c, c->d_state[s][a], cap * sizeof(float4)))) return rc;
+        if ((rc = ensure(c, c->d_state[s][3], cap * sizeof(uint2)))) return rc;
+    }
+    if ((rc = ensure(c, c->d_hits, cap * sizeof(float4)))) return rc;
+    if ((rc = ensure(c, c->d_radiance, cap * sizeof(float4)))) return rc;
+    if ((rc = ensure(c, c->d_counts, 16))) return rc;
+    if ((rc = ensure(c, c->d_rays, 16))) return rc;
+    if ((rc = ensure(c, c->d_overflow, 16))) return rc;
+    c->capacity = cap;
+    return RT_OK;
+}
+rtk::PathState path_state(rt_ctx* c, int s) {
+    rtk::PathState p;
+    p.o_time = (float4*)c->d_state[s][0].p;
+    p.d_slot = (float4*)c->d_state[s][1].p;
+    p.thr_meta = (float4*)c->d_state[s][2].p;
+    p.key = (uint2*)c->d_state[s][3].p;
+    return p;
+}
+
+// ---- event profiling -------------------------------------------------------------
+int ev_get(rt_ctx* c, int& idx) {
+    if (c->ev_next == c->ev_pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    idx = (int)c->ev_next++;
+    return RT_OK;
+}
+struct ScopedTimer {
+    rt_ctx* c;
+    int slot, i0 = -1, i1 = -1;
+    bool on;
+    ScopedTimer(rt_ctx* ctx, int s) : c(ctx), slot(s), on(ctx->profile) {
+        if (on && ev_get(c, i0) == RT_OK) (void)hipEventRecord(c->ev_pool[i0], c->stream);
+    }
+    ~ScopedTimer() {
+        if (on && i0 >= 0 && ev_get(c, i1) == RT_OK) {
+            (void)hipEventRecord(c->ev_pool[i1], c->stream);
+            c->ev_used.push_back({slot, {i0, i1}});
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rt_ctx_create(int device, rt_ctx** out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return RT_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return RT_ERR_HIP;
+    rt_ctx* c = new rt_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return RT_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    if (hipHostMalloc((void**)&c->h_counts, 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_rays, 64, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return RT_ERR_HIP;
+    }
+    c->max_paths = (uint64_t)env_u32("RTAMD_MAX_PATHS_MI", 16) << 20;
+    *out = c;
+    return RT_OK;
+}
+
+void rt_ctx_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->d_prims, &c->d_moving, &c->d_nodes, &c->d_groups, &c->d_mats, &c->d_texs, &c->d_perlin,
+                      &c->d_images, &c->d_hits, &c->d_radiance, &c->d_counts, &c->d_rays, &c->d_overflow, &c->d_pixels,
+                      &c->d_accum};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& b : c->d_image_data) b.release();
+    for (int s = 0; s < 2; s++)
+        for (int a = 0; a < 4; a++) c->d_state[s][a].release();
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->h_rays) (void)hipHostFree(c->h_rays);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rt_ctx_set_stream(rt_ctx* c, void* hip_stream) {
+    if (!c) return RT_ERR_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RT_OK;
+}
+int rt_ctx_set_max_paths(rt_ctx* c, uint64_t max_paths) {
+    if (!c || max_paths < 1024 || max_paths > (1ull << 31)) return fail(c, RT_ERR_INVALID, "max_paths out of range");
+    c->max_paths = max_paths;
+    return RT_OK;
+}
+int rt_ctx_synchronize(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_scene_clear(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    c->sph = HostSpheres();
+    c->rect = HostRects();
+    c->groups.clear();
+    c->mats.clear();
+    c->texs.clear();
+    c->perlin_vec.clear();
+    c->perlin_perm.clear();
+    c->images.clear();
+    c->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_set_spheres(rt_ctx* c, uint32_t n, const float* c0_r, const float* c1, const float* t01,
+                         const uint8_t* moving, const uint32_t* mat, const uint32_t* id, const uint32_t* group) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!c0_r || !mat || !id)) return fail(c, RT_ERR_INVALID, "rt_scene_set_spheres: null array");
+    if (moving && (!c1 || !t01)) return fail(c, RT_ERR_INVALID, "rt_scene_set_spheres: moving flags need c1 and t01");
+    HostSpheres& s = c->sph;
+    s = HostSpheres();
+    s.n = n;
+    s.c0r.assign(c0_r, c0_r + 4 * (size_t)n);
+    if (moving) {
+        s.moving.assign(moving, moving + n);
+        s.c1.assign(c1, c1 + 3 * (size_t)n);
+        s.t01.assign(t01, t01 + 2 * (size_t)n);
+    }
+    s.mat.assign(mat, mat + n);
+    s.id.assign(id, id + n);
+    if (group)
+        s.group.assign(group, group + n);
+    else
+        s.group.assign(n, 0u);
+    c->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_set_rects(rt_ctx* c, uint32_t n, const uint8_t* axis, const float* k, const float* bounds,
+                       const uint32_t* mat, const uint32_t* id, const uint32_t* group) {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!axis || !k || !bounds || !mat || !id)) return fail(c, RT_ERR_INVALID, "rt_scene_set_rects: null array");
+    for (uint32_t i = 0; i < n; i++)
+        if (axis[i] > 2) return fail(c, RT_ERR_INVALID, "rt_scene_set_rects: axis must be 0, 1 or 2");
+    HostRects& r = c->rect;
+    r = HostRects();
+    r.n = n;
+    r.axis.assign(axis, axis + n);
+    r.k.assign(k, k + n);
+    r.bounds.assign(bounds, bounds + 4 * (size_t)n);
+    r.mat.assign(mat, mat + n);
+    r.id.assign(id, id + n);
+    if (group)
+        r.group.assign(group, group + n);
+    else
+        r.group.assign(n, 0u);
+    c->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_set_groups(rt_ctx* c, uint32_t n, const rt_group* groups) {
+    if (!c || (n && !groups)) return fail(c, RT_ERR_INVALID, "rt_scene_set_groups: null array");
+    for (uint32_t i = 0; i < n; i++)
+        if (groups[i].kind != RT_GROUP_INSTANCE && groups[i].kind != RT_GROUP_MEDIUM)
+            return fail(c, RT_ERR_INVALID, "rt_scene_set_groups: unknown group kind");
+    c->groups.assign(groups, groups + n);
+    c->committed = false;
+    return RT_OK;
+}
+int rt_scene_set_materials(rt_ctx* c, uint32_t n, const rt_material* mats) {
+    if (!c || (n && !mats)) return fail(c, RT_ERR_INVALID, "rt_scene_set_materials: null array");
+    for (uint32_t i = 0; i < n; i++)
+        if (mats[i].kind > RT_MAT_ISOTROPIC) return fail(c, RT_ERR_INVALID, "rt_scene_set_materials: unknown kind");
+    if (n >= (1u << 24)) return fail(c, RT_ERR_UNSUPPORTED, "more than 2^24 materials");
+    c->mats.assign(mats, mats + n);
+    c->committed = false;
+    return RT_OK;
+}
+int rt_scene_set_textures(rt_ctx* c, uint32_t n, const rt_texture* texs) {
+    if (!c || (n && !texs)) return fail(c, RT_ERR_INVALID, "rt_scene_set_textures: null array");
+    for (uint32_t i = 0; i < n; i++)
+        if (texs[i].kind > RT_TEX_IMAGE) return fail(c, RT_ERR_INVALID, "rt_scene_set_textures: unknown kind");
+    c->texs.assign(texs, texs + n);
+    c->committed = false;
+    return RT_OK;
+}
+int rt_scene_set_perlin(rt_ctx* c, uint32_t table, const float* vec, const int32_t* perm) {
+    if (!c || !vec || !perm || table >= 1024) return fail(c, RT_ERR_INVALID, "rt_scene_set_perlin: bad argument");
+    for (int i = 0; i < 768; i++)
+        if (perm[i] < 0 || perm[i] > 255) return fail(c, RT_ERR_INVALID, "rt_scene_set_perlin: perm entry outside 0..255");
+    c->perlin_vec[table].assign(vec, vec + 768);
+    c->perlin_perm[table].assign(perm, perm + 768);
+    c->committed = false;
+    return RT_OK;
+}
+int rt_scene_set_image(rt_ctx* c, uint32_t table, uint32_t w, uint32_t h, const uint8_t* rgb) {
+    if (!c || !rgb || !w || !h || table >= 1024) return fail(c, RT_ERR_INVALID, "rt_scene_set_image: bad argument");
+    HostImage& im = c->images[table];
+    im.w = w;
+    im.h = h;
+    im.rgb.assign(rgb, rgb + 3 * (size_t)w * h);
+    c->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto tstart = std::chrono::steady_clock::now();
+    c->committed = false;
+    const uint32_t ng = (uint32_t)c->groups.size();
+    const uint64_t total_prims = (uint64_t)c->sph.n + c->rect.n;
+    if (total_prims >= rtd::MAX_PRIMS) return fail(c, RT_ERR_UNSUPPORTED, "more than 2^26 primitives");
+    // validate references
+    const uint32_t nm = (uint32_t)c->mats.size(), nt = (uint32_t)c->texs.size();
+    for (uint32_t i = 0; i < c->sph.n; i++)
+        if (c->sph.mat[i] >= nm || c->sph.group[i] > ng) return fail(c, RT_ERR_INVALID, "sphere: material or group out of range");
+    for (uint32_t i = 0; i < c->rect.n; i++)
+        if (c->rect.mat[i] >= nm || c->rect.group[i] > ng) return fail(c, RT_ERR_INVALID, "rect: material or group out of range");
+    for (const rt_material& m : c->mats)
+        if ((m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC) && m.tex >= nt)
+            return fail(c, RT_ERR_INVALID, "material: texture out of range");
+    uint32_t n_perlin = 0, n_images = 0;
+    for (const rt_texture& t : c->texs) {
+        if (t.kind == RT_TEX_CHECKER && (t.odd >= nt || t.even >= nt)) return fail(c, RT_ERR_INVALID, "checker: child texture out of range");
+        if (t.kind == RT_TEX_NOISE) {
+            if (!c->perlin_vec.count(t.table)) return fail(c, RT_ERR_INVALID, "noise texture: perlin table not set");
+            n_perlin = std::max(n_perlin, t.table + 1);
+        }
+        if (t.kind == RT_TEX_IMAGE) {
+            if (!c->images.count(t.table)) return fail(c, RT_ERR_INVALID, "image texture: image not set");
+            n_images = std::max(n_images, t.table + 1);
+        }
+    }
+    for (const rt_group& g : c->groups)
+        if (g.kind == RT_GROUP_MEDIUM && g.mat >= nm) return fail(c, RT_ERR_INVALID, "medium: material out of range");
+
+    // bucket primitives by group, in id order inside a group (Scene::intersect order for medium boundaries)
+    std::vector<std::vector<PrimSrc>> members(ng + 1);
+    for (uint32_t i = 0; i < c->sph.n; i++) members[c->sph.group[i]].push_back({true, i});
+    for (uint32_t i = 0; i < c->rect.n; i++) members[c->rect.group[i]].push_back({false, i});
+    auto id_of = [&](const PrimSrc& s) { return s.sphere ? c->sph.id[s.idx] : c->rect.id[s.idx]; };
+    for (auto& v : members) std::sort(v.begin(), v.end(), [&](const PrimSrc& a, const PrimSrc& b) { return id_of(a) < id_of(b); });
+
+    const uint32_t leaf_max = std::max(1u, std::min(env_u32("RTAMD_LEAF_MAX", 4), rtd::MAX_LEAF_PRIMS));
+    std::vector<rtd::Node> nodes;
+    std::vector<rtd::Prim> prims;
+    std::vector<rtd::Moving> moving;
+    std::vector<rtd::Group> dgroups(ng);
+    prims.reserve(total_prims);
+    auto prim_box = [&](const PrimSrc& s, float lo[3], float hi[3]) {
+        if (s.sphere)
+            sphere_box(c, s.idx, shutter_t0, shutter_t1, lo, hi);
+        else
+            rect_box(c, s.idx, lo, hi);
+        widen(lo, hi);
+    };
+
+    std::vector<rtb::Item> top;
+    uint32_t blas_depth = 0, n_media = 0, n_inst = 0;
+    // groups first: each gets a contiguous primitive range and (for instances) its own BVH
+    for (uint32_t g = 0; g < ng; g++) {
+        const rt_group& G = c->groups[g];
+        const auto& mem = members[g + 1];
+        rtd::Group& D = dgroups[g];
+        memcpy(D.m, G.m, sizeof(D.m));
+        memcpy(D.minv, G.minv, sizeof(D.minv));
+        D.neg_inv_density = G.neg_inv_density;
+        D.mat = G.mat;
+        D.kind = G.kind;
+        D.has_xform = G.has_xform ? 1u : 0u;
+        D.root_ref = rtd::REF_EMPTY;
+        D.order = G.kind == RT_GROUP_MEDIUM ? n_media++ : n_inst++;
+        if (mem.empty()) continue;
+        std::vector<rtb::Item> items(mem.size());
+        float glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = 0; i < mem.size(); i++) {
+            prim_box(mem[i], items[i].lo, items[i].hi);
+            items[i].payload = (uint32_t)i;
+            items[i].type = rtd::REF_PRIMS;
+            for (int k = 0; k < 3; k++) {
+                glo[k] = std::min(glo[k], items[i].lo[k]);
+                ghi[k] = std::max(ghi[k], items[i].hi[k]);
+            }
+        }
+        const bool medium = G.kind == RT_GROUP_MEDIUM;
+        if (medium && mem.size() > rtd::MAX_LEAF_PRIMS)
+            return fail(c, RT_ERR_UNSUPPORTED, "medium boundary with more than 16 primitives");
+        const bool single = medium || mem.size() <= 8;
+        std::vector<uint32_t> order;
+        const uint32_t base = (uint32_t)prims.size();
+        rtb::Result r = rtb::build(items, leaf_max, single, base, nodes, order);
+        for (uint32_t oi : order) prims.push_back(make_prim(c, mem[oi], moving));
+        D.root_ref = r.root_ref;
+        if (!medium) blas_depth = std::max(blas_depth, r.depth);
+        rtb::Item it;
+        if (G.has_xform) {
+            xform_box(G.m, glo, ghi, it.lo, it.hi);
+            widen(it.lo, it.hi);
+        } else {
+            memcpy(it.lo, glo, sizeof(glo));
+            memcpy(it.hi, ghi, sizeof(ghi));
+        }
+        it.payload = g;
+        it.type = medium ? rtd::REF_MEDIUM : rtd::REF_INSTANCE;
+        top.push_back(it);
+    }
+    // top level: world primitives + groups
+    const auto& world = members[0];
+    const size_t n_group_items = top.size();
+    top.resize(n_group_items + world.size());
+    for (size_t i = 0; i < world.size(); i++) {
+        rtb::Item& it = top[n_group_items + i];
+        prim_box(world[i], it.lo, it.hi);
+        it.payload = (uint32_t)i;
+        it.type = rtd::REF_PRIMS;
+    }
+    std::vector<uint32_t> order;
+    const uint32_t base = (uint32_t)prims.size();
+    rtb::Result top_r = rtb::build(top, leaf_max, false, base, nodes, order);
+    for (uint32_t oi : order) prims.push_back(make_prim(c, world[oi], moving));
+
+    uint32_t need = top_r.depth + (n_inst ? 1 + blas_depth : 0) + 1;
+    if (need > 64) return fail(c, RT_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack");
+    c->stack_entries = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+    c->has_groups = ng > 0;
+
+    // upload
+    int rc;
+    if ((rc = upload(c, c->d_prims, prims.data(), prims.size() * sizeof(rtd::Prim)))) return rc;
+    if ((rc = upload(c, c->d_moving, moving.data(), moving.size() * sizeof(rtd::Moving)))) return rc;
+    if ((rc = upload(c, c->d_nodes, nodes.data(), nodes.size() * sizeof(rtd::Node)))) return rc;
+    if ((rc = upload(c, c->d_groups, dgroups.data(), dgroups.size() * sizeof(rtd::Group)))) return rc;
+    static_assert(sizeof(rt_material) == sizeof(rtd::Material), "material layout");
+    static_assert(sizeof(rt_texture) == sizeof(rtd::Texture), "texture layout");
+    if ((rc = upload(c, c->d_mats, c->mats.data(), c->mats.size() * sizeof(rt_material)))) return rc;
+    if ((rc = upload(c, c->d_texs, c->texs.data(), c->texs.size() * sizeof(rt_texture)))) return rc;
+    std::vector<rtd::PerlinTable> ptab(n_perlin);
+    for (uint32_t t = 0; t < n_perlin; t++) {
+        memset(&ptab[t], 0, sizeof(rtd::PerlinTable));
+        if (!c->perlin_vec.count(t)) continue;
+        const auto& v = c->perlin_vec[t];
+        const auto& p = c->perlin_perm[t];
+        for (int i = 0; i < 256; i++)
+            for (int k = 0; k < 3; k++) ptab[t].vec[i][k] = v[3 * i + k];
+        for (int a = 0; a < 3; a++)
+            for (int i = 0; i < 256; i++) ptab[t].perm[a][i] = p[256 * a + i];
+    }
+    if ((rc = upload(c, c->d_perlin, ptab.data(), ptab.size() * sizeof(rtd::PerlinTable)))) return rc;
+    for (auto& b : c->d_image_data) b.release();
+    c->d_image_data.assign(n_images, DevBuf());
+    std::vector<rtd::Image> dimg(n_images);
+    uint64_t image_bytes = 0;
+    for (uint32_t t = 0; t < n_images; t++) {
+        dimg[t] = rtd::Image{nullptr, 0, 0};
+        if (!c->images.count(t)) continue;
+        const HostImage& im = c->images[t];
+        if ((rc = upload(c, c->d_image_data[t], im.rgb.data(), im.rgb.size()))) return rc;
+        dimg[t] = rtd::Image{(const uint8_t*)c->d_image_data[t].p, im.w, im.h};
+        image_bytes += im.rgb.size();
+    }
+    if ((rc = upload(c, c->d_images, dimg.data(), dimg.size() * sizeof(rtd::Image)))) return rc;
+
+    rtd::Scene& S = c->scene;
+    S.prims = (const rtd::Prim*)c->d_prims.p;
+    S.moving = (const rtd::Moving*)c->d_moving.p;
+    S.nodes = (const rtd::Node*)c->d_nodes.p;
+    S.groups = (const rtd::Group*)c->d_groups.p;
+    S.mats = (const rtd::Material*)c->d_mats.p;
+    S.texs = (const rtd::Texture*)c->d_texs.p;
+    S.perlin = (const rtd::PerlinTable*)c->d_perlin.p;
+    S.images = (const rtd::Image*)c->d_images.p;
+    S.root_ref = top_r.root_ref;
+    S.n_prims = (uint32_t)prims.size();
+    S.n_groups = ng;
+    S.n_media = n_media;
+
+    c->info.n_prims = prims.size();
+    c->info.n_nodes = nodes.size();
+    c->info.n_groups = ng;
+    c->info.n_media = n_media;
+    c->info.max_depth = need;
+    c->info.stack_entries = (uint32_t)c->stack_entries;
+    c->info.device_bytes = prims.size() * sizeof(rtd::Prim) + moving.size() * sizeof(rtd::Moving) +
+                           nodes.size() * sizeof(rtd::Node) + dgroups.size() * sizeof(rtd::Group) +
+                           c->mats.size() * sizeof(rt_material) + c->texs.size() * sizeof(rt_texture) +
+                           ptab.size() * sizeof(rtd::PerlinTable) + image_bytes;
+    c->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
+    c->committed = true;
+    return RT_OK;
+}
+
+int rt_scene_get_info(rt_ctx* c, rt_scene_info* out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    if (!c->committed) return fail(c, RT_ERR_NOT_COMMITTED, "scene not committed");
+    *out = c->info;
+    return RT_OK;
+}
+
+int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                       const float* dy, const float* dz, const float* time, float tmin, float tmax, uint32_t seed,
+                       int32_t* prim, int32_t* inst, float* t, float* normal, uint8_t* front, float* uv, float* point) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->committed) return fail(c, RT_ERR_NOT_COMMITTED, "rt_intersect_batch before rt_scene_commit");
+    if (n == 0) return RT_OK;
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !time) return fail(c, RT_ERR_INVALID, "rt_intersect_batch: null ray array");
+    if (n > (1ull << 32)) return fail(c, RT_ERR_INVALID, "rt_intersect_batch: more than 2^32 rays");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float* in[7] = {ox, oy, oz, dx, dy, dz, time};
+    const bool dev = is_device_ptr(ox);
+    int rc;
+    if ((rc = ensure(c, c->d_overflow, 16))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
+    if (dev) {
+        HIP_TRY(c, rtk::launch_intersect_batch(c->stream, c->stack_entries, c->has_groups, c->scene, n, in, tmin, tmax,
+                                               seed, prim, inst, t, normal, front, uv, point, (uint32_t*)c->d_overflow.p));
+    } else {
+        // staging for host callers: rays in, requested outputs back
+        DevBuf din, dout;
+        size_t out_bytes = n * (4 + 4 + 4 + 12 + 4 + 8 + 12);
+        if ((rc = ensure(c, din, n * 7 * sizeof(float))) || (rc = ensure(c, dout, out_bytes))) {
+            din.release();
+            dout.release();
+            return rc;
+        }
+        float* dr = (float*)din.p;
+        const float* drays[7];
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 7 && e == hipSuccess; k++) {
+            drays[k] = dr + (size_t)k * n;
+            e = hipMemcpyAsync(dr + (size_t)k * n, in[k], n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        }
+        char* o = (char*)dout.p;
+        int32_t* d_prim = (int32_t*)o;
+        int32_t* d_inst = (int32_t*)(o + 4 * n);
+        float* d_t = (float*)(o + 8 * n);
+        float* d_normal = (float*)(o + 12 * n);
+        uint8_t* d_front = (uint8_t*)(o + 24 * n);
+        float* d_uv = (float*)(o + 28 * n);
+        float* d_point = (float*)(o + 36 * n);
+        if (e == hipSuccess)
+            e = rtk::launch_intersect_batch(c->stream, c->stack_entries, c->has_groups, c->scene, n, drays, tmin, tmax, seed,
+                                            prim ? d_prim : nullptr, inst ? d_inst : nullptr, t ? d_t : nullptr,
+                                            normal ? d_normal : nullptr, front ? d_front : nullptr, uv ? d_uv : nullptr,
+                                            point ? d_point : nullptr, (uint32_t*)c->d_overflow.p);
+        auto back = [&](void* dst, const void* src, size_t bytes) {
+            if (dst && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+        };
+        back(prim, d_prim, 4 * n);
+        back(inst, d_inst, 4 * n);
+        back(t, d_t, 4 * n);
+        back(normal, d_normal, 12 * n);
+        back(front, d_front, n);
+        back(uv, d_uv, 8 * n);
+        back(point, d_point, 12 * n);
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        din.release();
+        dout.release();
+        if (e != hipSuccess) return hip_fail(c, e, "rt_intersect_batch staging");
+        if (e2 != hipSuccess) return hip_fail(c, e2, "rt_intersect_batch sync");
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_counts + 2, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_counts[2]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
+    return RT_OK;
+}
+
+int rt_owned_pixels(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t rank, uint32_t nranks, uint32_t* out,
+                    uint64_t cap, uint64_t* n_out) {
+    if (!n_out || !width || !height) return RT_ERR_INVALID;
+    if (!tile_size) tile_size = 32;
+    if (!nranks) nranks = 1;
+    if (rank >= nranks) return RT_ERR_INVALID;
+    const uint32_t tx = (width + tile_size - 1) / tile_size, ty = (height + tile_size - 1) / tile_size;
+    uint64_t n = 0;
+    for (uint64_t tile = rank; tile < (uint64_t)tx * ty; tile += nranks) {
+        uint32_t x0 = (uint32_t)(tile % tx) * tile_size, y0 = (uint32_t)(tile / tx) * tile_size;
+        uint32_t x1 = std::min(width, x0 + tile_size), y1 = std::min(height, y0 + tile_size);
+        for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t x = x0; x < x1; x++) {
+                if (out && n < cap) out[n] = y * width + x;
+                n++;
+            }
+    }
+    *n_out = n;
+    return RT_OK;
+}
+
+int rt_profile_enable(rt_ctx* c, int on) {
+    if (!c) return RT_ERR_INVALID;
+    c->profile = on != 0;
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float* accum_rgb, rt_render_stats* stats) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->committed) return fail(c, RT_ERR_NOT_COMMITTED, "rt_render before rt_scene_commit");
+    if (!cam || !p || !accum_rgb) return fail(c, RT_ERR_INVALID, "rt_render: null argument");
+    if (p->width < 2 || p->height < 2 || (uint64_t)p->width * p->height > (1ull << 31))
+        return fail(c, RT_ERR_INVALID, "rt_render: image size out of range");
+    if (p->sample1 < p->sample0) return fail(c, RT_ERR_INVALID, "rt_render: sample1 < sample0");
+    if (p->max_depth == 0 || p->max_depth > 255) return fail(c, RT_ERR_INVALID, "rt_render: max_depth must be 1..255");
+    const uint32_t ts = p->tile_size ? p->tile_size : 32, nranks = p->nranks ? p->nranks : 1;
+    if (p->rank >= nranks) return fail(c, RT_ERR_INVALID, "rt_render: rank >= nranks");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto wall0 = std::chrono::steady_clock::now();
+    int rc;
+
+    // owned pixel list (cached per frame geometry)
+    uint64_t key[5] = {p->width, p->height, ts, p->rank, nranks};
+    if (memcmp(key, c->pixels_key, sizeof(key)) != 0 || !c->d_pixels.p) {
+        uint64_t n = 0;
+        rt_owned_pixels(p->width, p->height, ts, p->rank, nranks, nullptr, 0, &n);
+        std::vector<uint32_t> px(n);
+        rt_owned_pixels(p->width, p->height, ts, p->rank, nranks, px.data(), n, &n);
+        if ((rc = upload(c, c->d_pixels, px.data(), n * sizeof(uint32_t)))) return rc;
+        memcpy(c->pixels_key, key, sizeof(key));
+        c->n_owned = n;
+    }
+    const uint64_t n_owned = c->n_owned;
+    const uint32_t n_samples_total = p->sample1 - p->sample0;
+
+    const bool accum_dev = is_device_ptr(accum_rgb);
+    const size_t accum_bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+    float* d_accum = accum_rgb;
+    if (!accum_dev) {
+        if ((rc = ensure(c, c->d_accum, accum_bytes))) return rc;
+        d_accum = (float*)c->d_accum.p;
+        HIP_TRY(c, hipMemcpyAsync(d_accum, accum_rgb, accum_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+
+    rtk::RenderConst rcst;
+    static_assert(sizeof(rt_camera) == sizeof(rtd::Camera), "camera layout");
+    memcpy(&rcst.cam, cam, sizeof(rt_camera));
+    memcpy(rcst.background, p->background, sizeof(float) * 3);
+    rcst.width = p->width;
+    rcst.height = p->height;
+    rcst.seed = p->seed;
+    rcst.max_depth = p->max_depth;
+
+    rt_render_stats st{};
+    c->ev_used.clear();
+    c->ev_next = 0;
+    if (n_owned && n_samples_total) {
+        const uint64_t cap = std::min<uint64_t>(c->max_paths, n_owned * (uint64_t)n_samples_total);
+        if ((rc = alloc_wavefront(c, std::max<uint64_t>(cap, 1024)))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
+        uint32_t* counts = (uint32_t*)c->d_counts.p;
+        const uint64_t pix_chunk = std::min<uint64_t>(n_owned, c->capacity);
+        for (uint64_t p0 = 0; p0 < n_owned; p0 += pix_chunk) {
+            const uint32_t npix = (uint32_t)std::min<uint64_t>(pix_chunk, n_owned - p0);
+            const uint32_t s_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_samples_total, c->capacity / npix));
+            const uint32_t* plist = (const uint32_t*)c->d_pixels.p + p0;
+            for (uint32_t s = 0; s < n_samples_total; s += s_batch) {
+                const uint32_t ns = std::min(s_batch, n_samples_total - s);
+                uint32_t n_bound = npix * ns;
+                st.batches++;
+                st.paths += n_bound;
+                {
+                    ScopedTimer tm(c, KS_RAYGEN);
+                    HIP_TRY(c, rtk::launch_raygen(c->stream, rcst, plist, npix, p->sample0 + s, ns, path_state(c, 0), counts,
+                                                  (float4*)c->d_radiance.p));
+                }
+                uint32_t which = 0;
+                for (uint32_t b = 0; b < p->max_depth; b++) {
+                    {
+                        ScopedTimer tm(c, KS_TRACE);
+                        HIP_TRY(c, rtk::launch_trace(c->stream, c->stack_entries, c->has_groups, c->scene, path_state(c, which),
+                                                     counts, which, n_bound, (float4*)c->d_hits.p,
+                                                     (unsigned long long*)c->d_rays.p, (uint32_t*)c->d_overflow.p));
+                    }
+                    {
+                        ScopedTimer tm(c, KS_SHADE);
+                        HIP_TRY(c, rtk::launch_shade(c->stream, c->scene, rcst, path_state(c, which), path_state(c, which ^ 1),
+                                                     (const float4*)c->d_hits.p, counts, which, n_bound,
+                                                     (float4*)c->d_radiance.p));
+                    }
+                    which ^= 1;
+                    st.bounce_launches++;
+                    // read the live-path count back now and then: stop when no path is left, shrink the grid
+                    const bool check = b < 4 || (b & 3) == 3;
+                    if (check && b + 1 < p->max_depth) {
+                        HIP_TRY(c, hipMemcpyAsync(c->h_counts, counts + which, 4, hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, hipStreamSynchronize(c->stream));
+                        n_bound = c->h_counts[0];
+                        if (n_bound == 0) break;
+                    }
+                }
+                {
+                    ScopedTimer tm(c, KS_ACCUM);
+                    HIP_TRY(c, rtk::launch_accumulate(c->stream, (const float4*)c->d_radiance.p, plist, npix, ns, d_accum));
+                }
+            }
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->h_rays, c->d_rays.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_counts + 2, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (!accum_dev) HIP_TRY(c, hipMemcpyAsync(accum_rgb, d_accum, accum_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_owned && n_samples_total) {
+        st.rays = *c->h_rays;
+        if (c->h_counts[2]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
+    }
+    if (c->profile) {
+        double ms[KS_COUNT] = {0, 0, 0, 0};
+        for (auto& u : c->ev_used) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, c->ev_pool[u.second.first], c->ev_pool[u.second.second]) == hipSuccess) ms[u.first] += t;
+            if (u.first == KS_TRACE) st.trace_launches++;
+            if (u.first == KS_SHADE) st.shade_launches++;
+        }
+        st.raygen_ms = ms[KS_RAYGEN];
+        st.trace_ms = ms[KS_TRACE];
+        st.shade_ms = ms[KS_SHADE];
+        st.accumulate_ms = ms[KS_ACCUM];
+    }
+    st.render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (stats) *stats = st;
+    return RT_OK;
+}
+
+int rt_resolve_u8(rt_ctx* c, const float* sum_rgb, uint64_t n_pixels, uint32_t spp, uint8_t* out) {
+    if (!c || !sum_rgb || !out || !spp) return fail(c, RT_ERR_INVALID, "rt_resolve_u8: bad argument");
+    if (n_pixels == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t n = n_pixels * 3;
+    const bool in_dev = is_device_ptr(sum_rgb), out_dev = is_device_ptr(out);
+    DevBuf din, dout;
+    int rc = RT_OK;
+    const float* d_in = sum_rgb;
+    uint8_t* d_out = out;
+    hipError_t e = hipSuccess;
+    if (!in_dev) {
+        if ((rc = ensure(c, din, n * sizeof(float)))) return rc;
+        e = hipMemcpyAsync(din.p, sum_rgb, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        d_in = (const float*)din.p;
+    }
+    if (!out_dev && e == hipSuccess) {
+        if ((rc = ensure(c, dout, n))) {
+            din.release();
+            return rc;
+        }
+        d_out = (uint8_t*)dout.p;
+    }
+    if (e == hipSuccess) e = rtk::launch_resolve(c->stream, d_in, n, spp, d_out);
+    if (!out_dev && e == hipSuccess) e = hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    din.release();
+    dout.release();
+    if (e != hipSuccess) return hip_fail(c, e, "rt_resolve_u8");
+    if (e2 != hipSuccess) return hip_fail(c, e2, "rt_resolve_u8 sync");
+    return RT_OK;
+}
+
+}  // extern "C"

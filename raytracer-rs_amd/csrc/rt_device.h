@@ -1,0 +1,114 @@
+// Device-side data layout shared by the host builder and the HIP kernels.
+//
+// Everything the kernels read lives in HBM as flat arrays:
+//   prims[]   32-B records in BVH leaf order (sphere: centre+radius, rect: plane+bounds),
+//   moving[]  32-B side records for moving spheres (second centre, shutter times),
+//   nodes[]   64-B inner nodes holding BOTH child boxes and both child references,
+//   groups[]  instance / medium descriptors (3x4 transforms, medium density, root reference),
+//   mats[], texs[], perlin[], images[].
+#pragma once
+#include <stdint.h>
+
+namespace rtd {
+
+// ---- child / root references (32 bit) ---------------------------------------
+// bits 31..30 type, for REF_PRIMS bits 29..26 = count-1, bits 25..0 = first prim
+constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t REF_SENTINEL = 0xFFFFFFFEu;  // traversal stack marker: leave instance space
+constexpr uint32_t REF_INNER = 0u, REF_PRIMS = 1u, REF_INSTANCE = 2u, REF_MEDIUM = 3u;
+constexpr uint32_t MAX_LEAF_PRIMS = 16u;
+constexpr uint32_t MAX_PRIMS = 1u << 26;
+inline uint32_t make_ref(uint32_t type, uint32_t index) { return (type << 30) | index; }
+inline uint32_t make_prim_ref(uint32_t first, uint32_t count) { return (REF_PRIMS << 30) | ((count - 1u) << 26) | first; }
+
+constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
+constexpr uint32_t HIT_MEDIUM_BIT = 0x80000000u;  // hit.prim = HIT_MEDIUM_BIT | group index
+constexpr uint32_t MEDIUM_KEY_BASE = 0x40000000u; // tie key of the k-th medium
+
+enum PrimKind : uint32_t { PK_SPHERE = 0, PK_MOVING_SPHERE = 1, PK_RECT_XY = 2, PK_RECT_XZ = 3, PK_RECT_YZ = 4 };
+
+struct alignas(32) Prim {
+    float a[4];     // sphere: cx,cy,cz,r        rect: k, min0, min1, max0
+    float b0;       // sphere: unused            rect: max1
+    uint32_t info;  // bits 2..0 PrimKind, bits 31..8 material index
+    uint32_t id;    // caller's flat id (tie key, reported by rt_intersect_batch)
+    uint32_t aux;   // moving sphere: index into moving[]
+};
+static_assert(sizeof(Prim) == 32, "Prim must be 32 B");
+
+struct alignas(32) Moving {
+    float c1[3];
+    float t0, t1;
+    float pad[3];
+};
+static_assert(sizeof(Moving) == 32, "Moving must be 32 B");
+
+struct alignas(64) Node {
+    float lo0[3], hi0[3];  // box of child 0
+    float lo1[3], hi1[3];  // box of child 1
+    uint32_t c0, c1;
+    uint32_t pad[2];
+};
+static_assert(sizeof(Node) == 64, "Node must be 64 B");
+
+struct alignas(16) Group {
+    float m[12];     // object -> world, rows
+    float minv[12];  // world -> object
+    double neg_inv_density;
+    uint32_t root_ref;  // instance: BLAS root; medium: REF_PRIMS list of the boundary
+    uint32_t mat;
+    uint32_t kind;      // 1 instance, 2 medium
+    uint32_t has_xform;
+    uint32_t order;     // instance: instance index; medium: medium index (RNG salt, reported id)
+    uint32_t pad;
+};
+static_assert(sizeof(Group) == 128, "Group must be 128 B");
+
+enum MatKind : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_LIGHT = 3, MK_ISOTROPIC = 4 };
+struct alignas(16) Material {
+    uint32_t kind, tex;
+    float albedo[3];
+    float fuzz, ior;
+    uint32_t pad;
+};
+static_assert(sizeof(Material) == 32, "Material must be 32 B");
+
+enum TexKind : uint32_t { TK_SOLID = 0, TK_CHECKER = 1, TK_NOISE = 2, TK_IMAGE = 3 };
+struct alignas(16) Texture {
+    uint32_t kind;
+    float color[3];
+    uint32_t odd, even;
+    float freq;
+    uint32_t table;
+};
+static_assert(sizeof(Texture) == 32, "Texture must be 32 B");
+
+struct alignas(16) PerlinTable {
+    float vec[256][4];
+    int32_t perm[3][256];
+};
+
+struct Image {
+    const uint8_t* rgb;
+    uint32_t w, h;
+};
+
+struct Camera {
+    float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius, time_start, time_end;
+};
+
+struct Scene {
+    const Prim* prims;
+    const Moving* moving;
+    const Node* nodes;
+    const Group* groups;
+    const Material* mats;
+    const Texture* texs;
+    const PerlinTable* perlin;
+    const Image* images;
+    uint32_t root_ref;
+    uint32_t n_prims, n_groups, n_media;
+};
+
+}  // namespace rtd

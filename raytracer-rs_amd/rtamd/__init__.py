@@ -1,0 +1,336 @@
+"""Python binding (ctypes) of the MI355X render path.
+
+Two shared libraries, built in-tree by ``make -C raytracer-rs_amd``:
+
+* ``lib/librtamd.so``  -- HIP kernels + the C ABI of ``include/rtamd.h``
+* ``lib/librthost.so`` -- C++ mirror of the reference's scene API and its scene builders
+
+There is no CPU fallback: importing works anywhere (so that symbols can be checked), but every
+work call needs a GPU and raises ``RtError`` otherwise.  Arrays may be numpy arrays (host) or
+torch CUDA tensors (device pointers are passed straight through).
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent.parent
+REPO_ROOT = PKG_DIR.parent
+LIB_DIR = PKG_DIR / "lib"
+EARTHMAP = REPO_ROOT / "tests" / "golden" / "earthmap.ppm"
+
+SCENES = ("random_world", "two_spheres", "two_perlin_spheres", "earth", "simple_light", "cornell_box",
+          "cornell_smoke", "final_scene", "synth_spheres")
+
+RT_OK = 0
+STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPPORTED", -4: "RT_ERR_NOT_COMMITTED",
+          -5: "RT_ERR_NO_DEVICE"}
+
+# every symbol include/rtamd.h declares
+ABI_SYMBOLS = (
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_ctx_set_stream", "rt_ctx_set_max_paths",
+    "rt_ctx_synchronize", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
+    "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
+    "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
+    "rt_resolve_u8", "rt_owned_pixels")
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class rt_camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+                ("lens_radius", C.c_float), ("time_start", C.c_float), ("time_end", C.c_float)]
+
+    def as_array(self):
+        return np.frombuffer(bytes(self), dtype=np.float32).copy()
+
+
+class rt_render_params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("sample0", C.c_uint32), ("sample1", C.c_uint32),
+                ("max_depth", C.c_uint32), ("background", C.c_float * 3), ("seed", C.c_uint32),
+                ("tile_size", C.c_uint32), ("rank", C.c_uint32), ("nranks", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class rt_render_stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("batches", C.c_uint32), ("bounce_launches", C.c_uint32),
+                ("render_ms", C.c_double), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
+                ("raygen_ms", C.c_double), ("accumulate_ms", C.c_double), ("trace_launches", C.c_uint64),
+                ("shade_launches", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class rt_scene_info(C.Structure):
+    _fields_ = [("n_prims", C.c_uint64), ("n_nodes", C.c_uint64), ("n_groups", C.c_uint64), ("n_media", C.c_uint64),
+                ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32), ("device_bytes", C.c_uint64),
+                ("build_seconds", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class rt_material(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("tex", C.c_uint32), ("albedo", C.c_float * 3), ("fuzz", C.c_float),
+                ("ior", C.c_float), ("reserved", C.c_uint32)]
+
+
+class rt_texture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("color", C.c_float * 3), ("odd", C.c_uint32), ("even", C.c_uint32),
+                ("freq", C.c_float), ("table", C.c_uint32)]
+
+
+class rt_group(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("has_xform", C.c_uint32), ("m", C.c_float * 12), ("minv", C.c_float * 12),
+                ("neg_inv_density", C.c_double), ("mat", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_core = None
+_host = None
+
+
+def _load(name):
+    path = LIB_DIR / name
+    if not path.exists():
+        raise RtError(-5, f"{path} is missing: build it with `make -C {PKG_DIR}` (needs hipcc); there is no CPU fallback")
+    return C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+
+
+def core():
+    """librtamd.so with argtypes set."""
+    global _core
+    if _core is not None:
+        return _core
+    L = _load("librtamd.so")
+    vp, u32, u64, f = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
+    L.rt_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rt_ctx_destroy.argtypes = [vp]
+    L.rt_ctx_destroy.restype = None
+    L.rt_last_error.argtypes = [vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_ctx_set_stream.argtypes = [vp, vp]
+    L.rt_ctx_set_max_paths.argtypes = [vp, u64]
+    L.rt_ctx_synchronize.argtypes = [vp]
+    L.rt_scene_clear.argtypes = [vp]
+    L.rt_scene_set_spheres.argtypes = [vp, u32] + [vp] * 7
+    L.rt_scene_set_rects.argtypes = [vp, u32] + [vp] * 6
+    L.rt_scene_set_groups.argtypes = [vp, u32, vp]
+    L.rt_scene_set_materials.argtypes = [vp, u32, vp]
+    L.rt_scene_set_textures.argtypes = [vp, u32, vp]
+    L.rt_scene_set_perlin.argtypes = [vp, u32, vp, vp]
+    L.rt_scene_set_image.argtypes = [vp, u32, u32, u32, vp]
+    L.rt_scene_commit.argtypes = [vp, f, f]
+    L.rt_scene_get_info.argtypes = [vp, C.POINTER(rt_scene_info)]
+    L.rt_intersect_batch.argtypes = [vp, u64] + [vp] * 7 + [f, f, u32] + [vp] * 7
+    L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, C.POINTER(rt_render_stats)]
+    L.rt_profile_enable.argtypes = [vp, C.c_int]
+    L.rt_resolve_u8.argtypes = [vp, vp, u64, u32, vp]
+    L.rt_owned_pixels.argtypes = [u32, u32, u32, u32, u32, vp, u64, C.POINTER(u64)]
+    for s in ABI_SYMBOLS:
+        fn = getattr(L, s)
+        if s not in ("rt_ctx_destroy", "rt_last_error"):
+            fn.restype = C.c_int
+    _core = L
+    return L
+
+
+def host():
+    """librthost.so (scene builders) with argtypes set."""
+    global _host
+    if _host is not None:
+        return _host
+    core()
+    H = _load("librthost.so")
+    vp = C.c_void_p
+    H.rth_scene_build.restype = vp
+    H.rth_scene_build.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_int64, C.c_char_p, C.c_int]
+    H.rth_scene_destroy.argtypes = [vp]
+    H.rth_scene_destroy.restype = None
+    H.rth_scene_upload.argtypes = [vp, vp, C.c_char_p, C.c_int]
+    H.rth_scene_upload.restype = C.c_int
+    H.rth_scene_preset.argtypes = [vp, C.POINTER(C.c_float)]
+    H.rth_scene_preset.restype = None
+    H.rth_scene_counts.argtypes = [vp, C.POINTER(C.c_int64)]
+    H.rth_scene_counts.restype = None
+    H.rth_scene_camera.argtypes = [vp, C.c_float, C.POINTER(rt_camera)]
+    H.rth_scene_camera.restype = None
+    H.rth_camera_new.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float] * 6 + [C.POINTER(rt_camera)]
+    H.rth_camera_new.restype = None
+    _host = H
+    return H
+
+
+def image_height(width, aspect):
+    """``(image_width as f32 / aspect_ratio) as u32`` (main.rs:383)."""
+    return int(np.float32(width) / np.float32(aspect))
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    """Raw pointer of a numpy array / torch tensor (or None)."""
+    if a is None:
+        return None
+    if _is_torch(a):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def camera_new(origin, target, up, vfov_rad, aspect, aperture, focus, t0, t1):
+    """Camera::new (camera.rs:28-52)."""
+    cam = rt_camera()
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    host().rth_camera_new(f3(origin), f3(target), f3(up), vfov_rad, aspect, aperture, focus, t0, t1, C.byref(cam))
+    return cam
+
+
+def owned_pixels(width, height, tile_size=32, rank=0, nranks=1):
+    n = C.c_uint64(0)
+    core().rt_owned_pixels(width, height, tile_size, rank, nranks, None, 0, C.byref(n))
+    out = np.empty(n.value, dtype=np.uint32)
+    core().rt_owned_pixels(width, height, tile_size, rank, nranks, _ptr(out), n.value, C.byref(n))
+    return out
+
+
+class Context:
+    """One GPU, one stream, one committed scene."""
+
+    def __init__(self, device=0, max_paths=None):
+        self.L = core()
+        h = C.c_void_p()
+        rc = self.L.rt_ctx_create(device, C.byref(h))
+        if rc != RT_OK:
+            raise RtError(rc, "rt_ctx_create failed (no GPU visible?)")
+        self.h = h
+        self.scene_handle = None
+        self.scene_name = None
+        if max_paths:
+            self._check(self.L.rt_ctx_set_max_paths(self.h, int(max_paths)))
+
+    def _check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, (self.L.rt_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "scene_handle", None):
+            host().rth_scene_destroy(self.scene_handle)
+            self.scene_handle = None
+        if getattr(self, "h", None):
+            self.L.rt_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.rt_ctx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def synchronize(self):
+        self._check(self.L.rt_ctx_synchronize(self.h))
+
+    def profile(self, on=True):
+        self._check(self.L.rt_profile_enable(self.h, 1 if on else 0))
+
+    # ---- scenes ------------------------------------------------------------------
+    def load_scene(self, name, seed=1, n_synth=0, earthmap=None):
+        """Build one of the reference's scenes through the C++ mirror API, flatten, upload, commit."""
+        H = host()
+        if self.scene_handle:
+            H.rth_scene_destroy(self.scene_handle)
+            self.scene_handle = None
+        err = C.create_string_buffer(512)
+        path = str(earthmap or EARTHMAP).encode()
+        h = H.rth_scene_build(name.encode(), seed, path, n_synth, err, len(err))
+        if not h:
+            raise RtError(-1, err.value.decode())
+        self.scene_handle = C.c_void_p(h)
+        rc = H.rth_scene_upload(self.scene_handle, self.h, err, len(err))
+        if rc != RT_OK:
+            raise RtError(rc, err.value.decode())
+        self.scene_name = name
+        cam = (C.c_float * 11)()
+        H.rth_scene_preset(self.scene_handle, cam)
+        self.cam_origin = np.array(cam[0:3], np.float32)
+        self.cam_target = np.array(cam[3:6], np.float32)
+        self.vfov_deg = float(cam[6])
+        self.aperture = float(cam[7])
+        self.background = np.array(cam[8:11], np.float32)
+        cnt = (C.c_int64 * 4)()
+        H.rth_scene_counts(self.scene_handle, cnt)
+        self.n_prims, self.n_instances, self.n_media, self.n_top = (int(x) for x in cnt)
+        return self.info()
+
+    def preset_camera(self, aspect):
+        cam = rt_camera()
+        host().rth_scene_camera(self.scene_handle, aspect, C.byref(cam))
+        return cam
+
+    def info(self):
+        inf = rt_scene_info()
+        self._check(self.L.rt_scene_get_info(self.h, C.byref(inf)))
+        return inf.as_dict()
+
+    # ---- work ----------------------------------------------------------------------
+    def intersect(self, rays, tmin=0.005, tmax=float("inf"), seed=1, outputs=None):
+        """rays: (7, n) float32 numpy array or torch CUDA tensor.  Returns a dict of arrays of the same kind."""
+        n = rays.shape[1]
+        if _is_torch(rays):
+            import torch
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=rays.device)
+            i32, f32, u8 = torch.int32, torch.float32, torch.uint8
+        else:
+            rays = np.ascontiguousarray(rays, dtype=np.float32)
+            mk = lambda shape, dt: np.empty(shape, dtype=dt)
+            i32, f32, u8 = np.int32, np.float32, np.uint8
+        out = dict(prim=mk((n,), i32), inst=mk((n,), i32), t=mk((n,), f32), normal=mk((n, 3), f32), front=mk((n,), u8),
+                   uv=mk((n, 2), f32), point=mk((n, 3), f32))
+        if outputs is not None:
+            out = {k: v for k, v in out.items() if k in outputs}
+        g = lambda k: _ptr(out.get(k))
+        self._check(self.L.rt_intersect_batch(self.h, n, *[_ptr(rays[i]) for i in range(7)], tmin, tmax, seed,
+                                              g("prim"), g("inst"), g("t"), g("normal"), g("front"), g("uv"), g("point")))
+        return out
+
+    def render(self, width, height, cam, spp, depth=50, seed=1, background=None, sample0=0, accum=None,
+               tile_size=32, rank=0, nranks=1):
+        """Adds samples [sample0, sample0+spp) into accum ((h,w,3) f32; numpy or torch CUDA) and returns
+        (accum, stats dict)."""
+        if accum is None:
+            accum = np.zeros((height, width, 3), dtype=np.float32)
+        p = rt_render_params()
+        p.width, p.height = width, height
+        p.sample0, p.sample1 = sample0, sample0 + spp
+        p.max_depth = depth
+        bg = self.background if background is None else background
+        p.background = (C.c_float * 3)(*[float(x) for x in bg])
+        p.seed = seed
+        p.tile_size, p.rank, p.nranks = tile_size, rank, nranks
+        st = rt_render_stats()
+        self._check(self.L.rt_render(self.h, C.byref(cam), C.byref(p), _ptr(accum), C.byref(st)))
+        return accum, st.as_dict()
+
+    def resolve_u8(self, accum, spp):
+        if _is_torch(accum):
+            import torch
+            out = torch.empty(accum.shape, dtype=torch.uint8, device=accum.device)
+        else:
+            out = np.empty(accum.shape, dtype=np.uint8)
+        n_pixels = int(np.prod(accum.shape)) // 3
+        self._check(self.L.rt_resolve_u8(self.h, _ptr(accum), n_pixels, spp, _ptr(out)))
+        return out
