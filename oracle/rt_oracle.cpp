@@ -7,6 +7,13 @@
 //   * ConstantMedium draws its free-flight sample from a stream position keyed on
 //     (path, bounce, medium) instead of "the next thread_rng value", so that the
 //     draw does not depend on traversal order;
+//   * world.intersect evaluates every ConstantMedium AFTER all surfaces, in creation
+//     order (world_intersect below).  A medium hit overrides the closest hit found so
+//     far even when it lies beyond it (shapes.rs:676-683 divides by the ray length
+//     twice, so final_t may exceed t_max; scene.rs:33-37 and bvh_node.rs:158-163 take
+//     the later result unchecked), which makes the reference's own answer depend on
+//     where its randomly built tree happens to visit the medium.  "Media last" is the
+//     order a Scene gets when its media are added last, as cornell_smoke does;
 //   * BVHNode::intersect resolves EXACT t ties between its two children towards the
 //     primitive created later (higher id).  The reference resolves them towards
 //     whichever child its randomly built tree visits second, i.e. not reproducibly;
@@ -245,6 +252,7 @@ struct PathCtx {
     double xi;
 };
 thread_local PathCtx* g_path = nullptr;
+thread_local bool g_media_deferred = false;  // see world_intersect
 thread_local uint64_t g_cnt_rays = 0, g_cnt_box = 0, g_cnt_prim = 0;
 
 // src/vec3_helpers.rs:7-60
@@ -513,8 +521,10 @@ struct IsotropicMat : Material {  // src/materials.rs:186-215
 // ----------------------------------------------------------------------------
 // Hittables (src/shapes.rs, src/scene.rs, src/bvh_node.rs)
 // ----------------------------------------------------------------------------
+struct Hittable;
 struct Ids {
     int prim = 0, inst = 0, medium = 0;
+    std::vector<const Hittable*> media;  // every ConstantMedium, in creation order
 };
 struct Hittable {
     virtual ~Hittable() {}
@@ -783,6 +793,7 @@ struct ConstantMedium : Hittable {  // src/shapes.rs:624-705
     ConstantMedium(HPtr b, float density, V3 color)
         : boundary(std::move(b)), negative_density(-1.0 / (double)density), material(std::make_shared<IsotropicMat>(color)) {}
     bool intersect(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+        if (g_media_deferred) return false;
         HitRecord r1, r2;
         if (!boundary->intersect(ray, -INF, INF, r1)) return false;
         if (!boundary->intersect(ray, r1.t + 0.0001f, INF, r2)) return false;
@@ -811,6 +822,7 @@ struct ConstantMedium : Hittable {  // src/shapes.rs:624-705
     bool bounding_box(float t0, float t1, AABB& out) const override { return boundary->bounding_box(t0, t1, out); }
     void assign_ids(Ids& ids) override {
         id = ids.medium++;
+        ids.media.push_back(this);
         boundary->assign_ids(ids);
     }
 };
@@ -952,8 +964,29 @@ inline Ray camera_sample_ray(const Camera& cam, int w, int h, int i, int j, Stre
     return cam.get_ray(u, v, rng);
 }
 
+// world.intersect with media evaluated last (see the file header)
+struct World {
+    const Hittable* surfaces;                 // the Scene or its BVHNode
+    const std::vector<const Hittable*>* media;  // top-level ConstantMedium objects, creation order
+    bool intersect(const Ray& ray, float t_min, float t_max, HitRecord& out) const {
+        g_media_deferred = true;
+        bool any = surfaces->intersect(ray, t_min, t_max, out);
+        g_media_deferred = false;
+        float closest = any ? out.t : t_max;
+        for (const Hittable* m : *media) {
+            HitRecord rec;
+            if (m->intersect(ray, t_min, closest, rec)) {  // scene.rs:33-37: taken unchecked
+                closest = rec.t;
+                out = rec;
+                any = true;
+            }
+        }
+        return any;
+    }
+};
+
 // src/main.rs:44-63
-V3 ray_color(const Ray& ray, V3 background, const Hittable& world, int depth, int max_depth) {
+V3 ray_color(const Ray& ray, V3 background, const World& world, int depth, int max_depth) {
     if (depth <= 0) return {0, 0, 0};
     g_path->bounce = (uint32_t)(max_depth - depth);
     g_cnt_rays++;
@@ -1192,9 +1225,8 @@ Camera scene_camera(const orc_scene& S, float aspect) {  // src/main.rs:454-456
     return Camera::make(S.cam_origin, S.cam_target, v3(0, 1, 0), degree_to_rad(S.vfov_deg), aspect, S.aperture, 10.0f,
                         0.0f, 1.0f);
 }
-const Hittable& world_of(const orc_scene& S, int mode) {
-    if (mode == 1) return *S.bvh;
-    return S.world;
+World world_of(const orc_scene& S, int mode) {
+    return World{mode == 1 ? static_cast<const Hittable*>(S.bvh.get()) : static_cast<const Hittable*>(&S.world), &S.ids.media};
 }
 Ray ray_from7(const float* r) { return Ray{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, r[6]}; }
 void rec_to_out(bool hit, const HitRecord& rec, float out[11]) {
@@ -1277,6 +1309,18 @@ void orc_scene_info(const orc_scene* s, int64_t info[4]) {
     info[2] = s->ids.medium;
     info[3] = (int64_t)s->world.shapes.size();
 }
+int64_t orc_scene_spheres(const orc_scene* s, int64_t cap, float* out) {
+    int64_t n = (int64_t)s->world.shapes.size();
+    for (int64_t i = 0; i < n && i < cap; i++) {
+        const Sphere* sp = dynamic_cast<const Sphere*>(s->world.shapes[i].get());
+        float nan = std::numeric_limits<float>::quiet_NaN();
+        out[4 * i] = sp ? sp->center.x : nan;
+        out[4 * i + 1] = sp ? sp->center.y : nan;
+        out[4 * i + 2] = sp ? sp->center.z : nan;
+        out[4 * i + 3] = sp ? sp->radius : nan;
+    }
+    return n;
+}
 void orc_scene_preset(const orc_scene* s, float cam[11]) {
     cam[0] = s->cam_origin.x;
     cam[1] = s->cam_origin.y;
@@ -1322,7 +1366,7 @@ int orc_intersect_batch(const orc_scene* S, int mode, int64_t n, const float* ox
                         uint32_t seed, int32_t* prim, int32_t* inst, float* t, float* normal, uint8_t* front, float* uv,
                         float* point, uint64_t* counters, int threads) {
     if (!S || n < 0) return -1;
-    const Hittable& world = world_of(*S, mode);
+    const World world = world_of(*S, mode);
     std::atomic<uint64_t> c_rays{0}, c_box{0}, c_prim{0};
     parallel_for(n, threads, [&](int64_t b, int64_t e, int) {
         g_cnt_rays = g_cnt_box = g_cnt_prim = 0;
@@ -1369,7 +1413,7 @@ int orc_gen_rays(const orc_scene* S, int w, int h, float aspect, uint32_t seed, 
                  uint8_t* valid) {
     if (!S || w < 2 || h < 2) return -1;
     Camera cam = scene_camera(*S, aspect);
-    const Hittable& world = *S->bvh;
+    const World world = world_of(*S, 1);
     int64_t n = (int64_t)w * h;
     for (int64_t p = 0; p < n; p++) {
         PathCtx ctx{path_stream(seed, (uint32_t)p, 0), 0, false, 0.0};
@@ -1405,7 +1449,7 @@ int orc_render(const orc_scene* S, int mode, int w, int h, float aspect, int s0,
                int x0, int y0, int x1, int y1, float* sum_rgb, uint64_t* rays_out, uint64_t* counters, int threads) {
     if (!S || w < 2 || h < 2 || s1 < s0 || x0 < 0 || y0 < 0 || x1 > w || y1 > h) return -1;
     Camera cam = scene_camera(*S, aspect);
-    const Hittable& world = world_of(*S, mode);
+    const World world = world_of(*S, mode);
     V3 bg = S->background;
     std::atomic<uint64_t> c_rays{0}, c_box{0}, c_prim{0};
     int64_t rows = y1 - y0;

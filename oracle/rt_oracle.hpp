@@ -42,6 +42,9 @@ orc_scene* orc_scene_create(const char* name, uint32_t seed,
 void orc_scene_destroy(orc_scene*);
 // info[0]=n_prims info[1]=n_instances info[2]=n_media info[3]=n_top_level
 void orc_scene_info(const orc_scene*, int64_t info[4]);
+// Top-level Sphere objects of the world list, in insertion order: out[4*i..] = cx,cy,cz,r
+// (NaN for anything that is not a plain Sphere).  Returns the number of top-level objects.
+int64_t orc_scene_spheres(const orc_scene*, int64_t cap, float* out);
 // preset camera of the scene: cam[0..2]=origin cam[3..5]=target cam[6]=vfov_deg
 // cam[7]=aperture cam[8..10]=background
 void orc_scene_preset(const orc_scene*, float cam[11]);

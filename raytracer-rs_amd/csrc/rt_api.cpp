@@ -68,7 +68,7 @@ struct rt_ctx {
 
     // device scene
     bool committed = false;
-    DevBuf d_prims, d_moving, d_nodes, d_groups, d_mats, d_texs, d_perlin, d_images;
+    DevBuf d_prims, d_moving, d_nodes, d_groups, d_mats, d_texs, d_perlin, d_images, d_media;
     std::vector<DevBuf> d_image_data;
     rtd::Scene scene{};
     int stack_entries = 16;
@@ -321,7 +321,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_prims, &c->d_moving, &c->d_nodes, &c->d_groups, &c->d_mats, &c->d_texs, &c->d_perlin,
-                      &c->d_images, &c->d_hits, &c->d_radiance, &c->d_counts, &c->d_rays, &c->d_overflow, &c->d_pixels,
+                      &c->d_images, &c->d_media, &c->d_hits, &c->d_radiance, &c->d_counts, &c->d_rays, &c->d_overflow, &c->d_pixels,
                       &c->d_accum};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->d_image_data) b.release();
@@ -512,6 +512,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     };
 
     std::vector<rtb::Item> top;
+    std::vector<uint32_t> media_groups;
     uint32_t blas_depth = 0, n_media = 0, n_inst = 0;
     // groups first: each gets a contiguous primitive range and (for instances) its own BVH
     for (uint32_t g = 0; g < ng; g++) {
@@ -541,6 +542,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         const bool medium = G.kind == RT_GROUP_MEDIUM;
         if (medium && mem.size() > rtd::MAX_LEAF_PRIMS)
             return fail(c, RT_ERR_UNSUPPORTED, "medium boundary with more than 16 primitives");
+        if (medium && media_groups.size() >= 64) return fail(c, RT_ERR_UNSUPPORTED, "more than 64 media");
         const bool single = medium || mem.size() <= 8;
         std::vector<uint32_t> order;
         const uint32_t base = (uint32_t)prims.size();
@@ -557,8 +559,11 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
             memcpy(it.hi, ghi, sizeof(ghi));
         }
         it.payload = g;
-        it.type = medium ? rtd::REF_MEDIUM : rtd::REF_INSTANCE;
-        top.push_back(it);
+        it.type = rtd::REF_INSTANCE;
+        if (medium)
+            media_groups.push_back(g);  // evaluated after the BVH walk, not a leaf
+        else
+            top.push_back(it);
     }
     // top level: world primitives + groups
     const auto& world = members[0];
@@ -586,6 +591,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     if ((rc = upload(c, c->d_moving, moving.data(), moving.size() * sizeof(rtd::Moving)))) return rc;
     if ((rc = upload(c, c->d_nodes, nodes.data(), nodes.size() * sizeof(rtd::Node)))) return rc;
     if ((rc = upload(c, c->d_groups, dgroups.data(), dgroups.size() * sizeof(rtd::Group)))) return rc;
+    if ((rc = upload(c, c->d_media, media_groups.data(), media_groups.size() * sizeof(uint32_t)))) return rc;
     static_assert(sizeof(rt_material) == sizeof(rtd::Material), "material layout");
     static_assert(sizeof(rt_texture) == sizeof(rtd::Texture), "texture layout");
     if ((rc = upload(c, c->d_mats, c->mats.data(), c->mats.size() * sizeof(rt_material)))) return rc;
@@ -625,6 +631,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.texs = (const rtd::Texture*)c->d_texs.p;
     S.perlin = (const rtd::PerlinTable*)c->d_perlin.p;
     S.images = (const rtd::Image*)c->d_images.p;
+    S.media = (const uint32_t*)c->d_media.p;
     S.root_ref = top_r.root_ref;
     S.n_prims = (uint32_t)prims.size();
     S.n_groups = ng;

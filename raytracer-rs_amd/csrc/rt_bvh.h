@@ -16,7 +16,7 @@ namespace rtb {
 struct Item {
     float lo[3], hi[3];
     uint32_t payload;  // primitive: index into the caller's primitive array; group: group index
-    uint32_t type;     // rtd::REF_PRIMS, rtd::REF_INSTANCE or rtd::REF_MEDIUM
+    uint32_t type;     // rtd::REF_PRIMS or rtd::REF_INSTANCE
 };
 
 struct Result {

@@ -15,7 +15,7 @@ namespace rtd {
 // bits 31..30 type, for REF_PRIMS bits 29..26 = count-1, bits 25..0 = first prim
 constexpr uint32_t REF_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t REF_SENTINEL = 0xFFFFFFFEu;  // traversal stack marker: leave instance space
-constexpr uint32_t REF_INNER = 0u, REF_PRIMS = 1u, REF_INSTANCE = 2u, REF_MEDIUM = 3u;
+constexpr uint32_t REF_INNER = 0u, REF_PRIMS = 1u, REF_INSTANCE = 2u;
 constexpr uint32_t MAX_LEAF_PRIMS = 16u;
 constexpr uint32_t MAX_PRIMS = 1u << 26;
 inline uint32_t make_ref(uint32_t type, uint32_t index) { return (type << 30) | index; }
@@ -55,7 +55,7 @@ struct alignas(16) Group {
     float m[12];     // object -> world, rows
     float minv[12];  // world -> object
     double neg_inv_density;
-    uint32_t root_ref;  // instance: BLAS root; medium: REF_PRIMS list of the boundary
+    uint32_t root_ref;  // instance: BLAS root; medium: REF_PRIMS list of the boundary (media are not BVH leaves)
     uint32_t mat;
     uint32_t kind;      // 1 instance, 2 medium
     uint32_t has_xform;
@@ -107,6 +107,7 @@ struct Scene {
     const Texture* texs;
     const PerlinTable* perlin;
     const Image* images;
+    const uint32_t* media;  // group indices of the media, in creation order (evaluated after the BVH walk)
     uint32_t root_ref;
     uint32_t n_prims, n_groups, n_media;
 };

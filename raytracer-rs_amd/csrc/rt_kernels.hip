@@ -191,7 +191,9 @@ DEV bool list_closest(const Scene& S, uint32_t ref, f3 o, f3 d, float a, float t
     return any;
 }
 
-// ConstantMedium::intersect (shapes.rs:648-701).  wo/wd: the world ray.
+// ConstantMedium::intersect (shapes.rs:648-701).  wo/wd: the world ray.  A medium that reports a hit
+// replaces the closest hit so far unchecked, as Scene::intersect does (scene.rs:33-37): its final_t may
+// lie beyond best.t because shapes.rs:676-683 divides by the ray length twice.
 DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1,
                      uint32_t bounce, Hit& best) {
     const Group& G = S.groups[g];
@@ -213,13 +215,10 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     double xi = medium_xi(k0, k1, bounce, G.order);
     double hit_distance = G.neg_inv_density * log(xi);
     if (hit_distance > inside) return;
-    float t = r1 + (float)(hit_distance / len);
-    uint32_t key = MEDIUM_KEY_BASE + G.order;
-    if (t == best.t && best.prim != HIT_NONE && key < best.key) return;
-    best.t = t;
+    best.t = r1 + (float)(hit_distance / len);
     best.prim = HIT_MEDIUM_BIT | g;
     best.grp = -1;
-    best.key = key;
+    best.key = MEDIUM_KEY_BASE + G.order;
 }
 
 DEV float pad_up(float x) { return x + __builtin_fabsf(x) * 6e-7f; }
@@ -249,12 +248,12 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
     best.grp = -1;
     best.key = 0;
     uint32_t cur = S.root_ref;
-    if (cur == REF_EMPTY) return;
     f3 o = wo, d = wd;
     float a = dot3(d, d);
     f3 inv = fast_rcp3(d);
     int grp = -1;
     int sp = 0;
+    if (cur == REF_EMPTY) goto surfaces_done;
     for (;;) {
         uint32_t type = cur >> 30;
         bool descend = false;
@@ -316,12 +315,10 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
                     inv = fast_rcp3(d);
                 }
             }
-        } else if (GROUPS && type == REF_MEDIUM) {
-            test_medium(S, cur & 0x3FFFFFFFu, wo, wd, time, tmin, k0, k1, bounce, best);
         }
         if (descend) continue;
         for (;;) {  // pop
-            if (sp == 0) return;
+            if (sp == 0) goto surfaces_done;
             sp--;
             cur = stk[sp * STRIDE];
             if (cur != REF_SENTINEL) break;
@@ -332,6 +329,10 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
             grp = -1;
         }
     }
+surfaces_done:
+    // media come after all surfaces, in creation order (the order of a Scene whose media were added last)
+    if (GROUPS)
+        for (uint32_t m = 0; m < S.n_media; m++) test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
 }
 
 // ---- hit record (hit_record.rs, shapes.rs) --------------------------------------

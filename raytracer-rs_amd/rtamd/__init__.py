@@ -16,7 +16,7 @@ import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent.parent
 REPO_ROOT = PKG_DIR.parent
-LIB_DIR = PKG_DIR / "lib"
+LIB_DIR = Path(__import__("os").environ.get("RTAMD_LIB_DIR", PKG_DIR / "lib"))
 EARTHMAP = REPO_ROOT / "tests" / "golden" / "earthmap.ppm"
 
 SCENES = ("random_world", "two_spheres", "two_perlin_spheres", "earth", "simple_light", "cornell_box",

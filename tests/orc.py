@@ -35,6 +35,8 @@ def lib():
     L.orc_scene_destroy.argtypes = [C.c_void_p]
     L.orc_scene_info.argtypes = [C.c_void_p, c_i64p]
     L.orc_scene_preset.argtypes = [C.c_void_p, c_fp]
+    L.orc_scene_spheres.restype = C.c_int64
+    L.orc_scene_spheres.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     L.orc_camera_new.argtypes = [c_fp, c_fp, c_fp, c_f, c_f, c_f, c_f, c_f, c_f, c_fp]
     L.orc_intersect_batch.restype = C.c_int
     L.orc_intersect_batch.argtypes = [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 7 + [c_f, c_f, C.c_uint32] + [C.c_void_p] * 8 + [C.c_int]
@@ -150,6 +152,12 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    def spheres(self):
+        """(n_top, 4) array cx,cy,cz,r of the top-level plain spheres (NaN rows for other objects)."""
+        out = np.empty((self.n_top, 4), dtype=np.float32)
+        lib().orc_scene_spheres(self.h, self.n_top, _ptr(out))
+        return out
 
     def gen_rays(self, w, h, aspect, seed=1, which=0):
         rays = np.zeros((7, w * h), dtype=np.float32)
