@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Throughput of the MI355X render hot path, on the metric BASELINE.json names: Mrays/s.
+
+One "step" renders the named workload once: every frame of the workload at its full size and
+sample count, the frame's tiles dealt round-robin over the ranks, each rank's tiles gathered into
+the complete frame on every rank with one all_gather (RCCL over xGMI) per frame.  Inputs (scene,
+BVH, textures, pixel lists) are resident in HBM before the timed region starts.
+
+  python bench.py                       # 1 GPU, default steps
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` is whole-job Mrays/s: rays traced by all ranks (one ray = one
+world.intersect call issued by ray_color, primary and scattered) divided by the max-over-ranks
+time of the K timed steps.  The same frame is split over the ranks, so scaling is "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "raytracer-rs_amd"))
+
+import torch  # noqa: E402
+
+import rtamd  # noqa: E402
+
+# BASELINE.json configs: name -> (frames, width, aspect, spp)
+WORKLOADS = {
+    # configs[1]: earth sphere with image texture + checker / noise textures, 1920x1080, 256 spp
+    "c2_textures": (("earth", "two_spheres", "two_perlin_spheres"), 1920, 16.0 / 9.0, 256),
+    # configs[0]: One Weekend random spheres, 400x225, 10 spp (the reference's own CPU-sized case)
+    "c1_random_world": (("random_world",), 400, 16.0 / 9.0, 10),
+    # configs[2]: random spheres with BVH + moving spheres, 1920x1080, 1024 spp
+    "c3_random_world": (("random_world",), 1920, 16.0 / 9.0, 1024),
+    # configs[3]: Cornell box + constant-medium volumes, 2048x2048, 4096 spp
+    "c4_cornell": (("cornell_box", "cornell_smoke"), 2048, 1.0, 4096),
+    # the north star's target scene: Next Week final scene, 800x800 (spp reduced from the binary's 10000)
+    "final_scene": (("final_scene",), 800, 1.0, 256),
+    # configs[4]: synthetic 10M-sphere scene, 3840x2160, 1024 spp
+    "c5_synth10m": (("synth_spheres",), 3840, 16.0 / 9.0, 1024),
+}
+MAX_DEPTH = 50
+PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class Frame:
+    """One scene of the workload on this rank: context, camera, accumulation buffer, gather plan."""
+
+    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=32):
+        self.name, self.w, self.spp = name, width, spp
+        self.h = rtamd.image_height(width, aspect)
+        self.rank, self.world = rank, world
+        self.ctx = rtamd.Context(device)
+        self.info = self.ctx.load_scene(name, seed=1, n_synth=n_synth)
+        self.ctx.use_torch_stream()
+        self.cam = self.ctx.preset_camera(aspect)
+        self.accum = torch.zeros((self.h, self.w, 3), dtype=torch.float32, device=f"cuda:{device}")
+        self.tile = tile
+        if world > 1:
+            owned = [rtamd.owned_pixels(self.w, self.h, tile, r, world) for r in range(world)]
+            self.pad = max(len(o) for o in owned)
+            dev = self.accum.device
+            self.my_idx = torch.from_numpy(owned[rank].astype(np.int64)).to(dev)
+            # destination pixel of every gathered slot; padding slots point one past the frame
+            dst = np.full((world, self.pad), self.w * self.h, dtype=np.int64)
+            for r, o in enumerate(owned):
+                dst[r, : len(o)] = o
+            self.dst_idx = torch.from_numpy(dst.reshape(-1)).to(dev)
+            self.packed = torch.zeros((self.pad, 3), dtype=torch.float32, device=dev)
+            self.gathered = torch.empty((world * self.pad, 3), dtype=torch.float32, device=dev)
+            self.full = torch.zeros((self.h * self.w + 1, 3), dtype=torch.float32, device=dev)
+
+    def render(self, spp=None):
+        self.accum.zero_()
+        _, st = self.ctx.render(self.w, self.h, self.cam, spp or self.spp, depth=MAX_DEPTH, seed=1, accum=self.accum,
+                                tile_size=self.tile, rank=self.rank, nranks=self.world)
+        if self.world > 1:
+            # framebuffer exchange: every rank owns disjoint tiles -> one all_gather of the packed tiles
+            self.packed[: self.my_idx.numel()] = self.accum.view(-1, 3)[self.my_idx]
+            torch.distributed.all_gather_into_tensor(self.gathered, self.packed)
+            self.full.index_copy_(0, self.dst_idx, self.gathered)
+        return st
+
+    def image(self):
+        if self.world > 1:
+            return self.full[:-1].view(self.h, self.w, 3)
+        return self.accum
+
+
+def trace_bytes_per_ray(info, nodes_per_ray, prims_per_ray):
+    """Algorithmic bytes one ray moves through k_trace: its state in (origin+time 16 B, direction+slot
+    16 B; scenes with media also key 8 B + meta 16 B), its hit record out (16 B), 64 B per inner node
+    fetched (two child boxes + two references) and 32 B per primitive record tested."""
+    state = 32 + 16 + (24 if info["n_groups"] else 0)
+    return state + 64.0 * nodes_per_ray + 32.0 * prims_per_ray
+
+
+def shade_bytes_per_ray(alive_frac):
+    """k_shade: path state in (56 B) + hit record (16 B) + primitive (32 B) + material (32 B) + texture
+    (32 B); out: the compacted state of surviving paths (56 B) or the radiance of ended ones (16 B)."""
+    return 56 + 16 + 32 + 32 + 32 + 56.0 * alive_frac + 16.0 * (1.0 - alive_frac)
+
+
+def cpu_baseline(frames_cfg, width, aspect, seconds_target=15.0):
+    """The CPU oracle (a port of the reference; the Rust binary cannot be built here) on a bounded
+    sample of the same workload: the same frames at full resolution and reduced spp, reference-style
+    pointer BVH, all host threads the box share allows."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import orc
+    threads = orc.DEFAULT_THREADS
+    h = rtamd.image_height(width, aspect)
+    rays_total, sec_total, spp_used = 0, 0.0, []
+    per_frame = seconds_target / len(frames_cfg)
+    for name in frames_cfg:
+        sc = orc.Scene(name, seed=1)
+        t0 = time.perf_counter()
+        _, rays = sc.render(width, h, aspect, 1, depth=MAX_DEPTH, seed=1, mode=1, threads=threads)
+        dt = time.perf_counter() - t0
+        spp = int(max(1, min(64, per_frame / max(dt, 1e-3) - 1)))
+        if spp > 1:
+            t0 = time.perf_counter()
+            _, rays2 = sc.render(width, h, aspect, spp, depth=MAX_DEPTH, seed=1, mode=1, s0=1, threads=threads)
+            dt += time.perf_counter() - t0
+            rays += rays2
+            spp += 1
+        rays_total += rays
+        sec_total += dt
+        spp_used.append(spp)
+        sc.close()
+    return {"value": rays_total / sec_total / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{'+'.join(frames_cfg)} at {width}x{h}, {'/'.join(map(str, spp_used))} spp each, depth {MAX_DEPTH}, "
+                      f"oracle BVHNode path (oracle/rt_oracle.cpp), {sec_total:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2_textures", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (changes the workload; recorded in config)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--synth-n", type=int, default=10_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing (roofline becomes null)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.gpus != world and rank == 0:
+        log(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+
+    frames_cfg, width, aspect, spp = WORKLOADS[args.workload]
+    width = args.width or width
+    spp = args.spp or spp
+    frames = [Frame(n, width, aspect, spp, rank, world, local_rank, args.synth_n) for n in frames_cfg]
+    for f in frames:
+        f.ctx.profile(events=not args.no_profile)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return [f.render() for f in frames]
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    my_rays = sum(st["rays"] for s in stats for st in s)
+    my_paths = sum(st["paths"] for s in stats for st in s)
+    t = torch.tensor([elapsed, float(my_rays), float(my_paths)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        tmax = t[:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        tsum = t[1:].clone()
+        torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+        elapsed, rays, paths = float(tmax[0]), float(tsum[0]), float(tsum[1])
+    else:
+        rays, paths = float(my_rays), float(my_paths)
+
+    out = None
+    if rank == 0:
+        # dominant kernel and its roofline, from HIP events recorded around every launch of the timed steps
+        roof = None
+        if not args.no_profile:
+            trace_ms = sum(st["trace_ms"] for s in stats for st in s)
+            shade_ms = sum(st["shade_ms"] for s in stats for st in s)
+            # per-ray node fetches / primitive tests of this workload: one instrumented pass at 1 spp (untimed)
+            tr_bytes = sh_bytes = 0.0
+            for f, st_frame in zip(frames, zip(*stats)):
+                f.ctx.profile(events=False, count_visits=True)
+                st = f.render(spp=1)
+                f.ctx.profile(events=True, count_visits=False)
+                nodes_pr = st["node_visits"] / max(st["rays"], 1)
+                prims_pr = st["prim_tests"] / max(st["rays"], 1)
+                f_rays = sum(s["rays"] for s in st_frame)
+                f_paths = sum(s["paths"] for s in st_frame)
+                alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
+                tr_bytes += f_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
+                sh_bytes += f_rays * shade_bytes_per_ray(alive)
+            n_tr = sum(st["trace_launches"] for s in stats for st in s)
+            n_sh = sum(st["shade_launches"] for s in stats for st in s)
+            if trace_ms >= shade_ms:
+                kernel, ms, nbytes, nl = "k_trace", trace_ms, tr_bytes, n_tr
+            else:
+                kernel, ms, nbytes, nl = "k_shade", shade_ms, sh_bytes, n_sh
+            achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,
+                    "launches": int(nl), "avg_launch_ms": round(ms / max(nl, 1), 5),
+                    "algorithmic_bytes_per_launch": round(nbytes / max(nl, 1), 1),
+                    "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3)}
+        out = {
+            "metric": "Mrays/s (paths x bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "frames": list(frames_cfg), "width": width, "height": frames[0].h,
+                       "spp": spp, "max_depth": MAX_DEPTH, "tile_split": f"32x32 tiles round-robin over {world} rank(s)",
+                       "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps,
+                       "sec_per_frame": round(elapsed / args.steps / len(frames), 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_cfg, width, aspect)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

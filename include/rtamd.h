@@ -172,14 +172,17 @@ typedef struct rt_render_stats {
     uint32_t batches;
     uint32_t bounce_launches;
     double render_ms;     /* wall time inside rt_render, device-synchronised */
-    double trace_ms, shade_ms, raygen_ms, accumulate_ms; /* HIP-event kernel time when profiling is on */
+    double trace_ms, shade_ms, raygen_ms, accumulate_ms; /* HIP-event kernel time (profile flag 1) */
     uint64_t trace_launches, shade_launches;
+    uint64_t node_visits; /* inner BVH nodes fetched   (profile flag 2, instrumented trace kernel) */
+    uint64_t prim_tests;  /* primitive records tested  (profile flag 2) */
 } rt_render_stats;
 
 int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* accum_rgb,
               rt_render_stats* stats);
-/* Time every kernel launch with HIP events on the context's stream (costs a little; off by default). */
-int rt_profile_enable(rt_ctx* ctx, int on);
+/* flags: 1 = time every kernel launch with HIP events on the context's stream; 2 = run the instrumented
+ * trace kernel that counts node fetches and primitive tests (slower).  0 = off (default). */
+int rt_profile_enable(rt_ctx* ctx, int flags);
 
 /* vec3_to_rgb(color * inv_samples) (main.rs:307-313,460,481): out[i] = (256*clamp(sum[i]/spp,0,0.999)) as u8.
  * sum_rgb and out: host or device. */

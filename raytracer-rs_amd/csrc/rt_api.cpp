@@ -86,6 +86,7 @@ struct rt_ctx {
 
     // profiling
     bool profile = false;
+    bool count_visits = false;
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, std::pair<int, int>>> ev_used;  // slot, (start idx, stop idx)
     size_t ev_next = 0;
@@ -245,7 +246,7 @@ int alloc_wavefront(rt_ctx* c, uint64_t cap) {
     if ((rc = ensure(c, c->d_hits, cap * sizeof(float4)))) return rc;
     if ((rc = ensure(c, c->d_radiance, cap * sizeof(float4)))) return rc;
     if ((rc = ensure(c, c->d_counts, 16))) return rc;
-    if ((rc = ensure(c, c->d_rays, 16))) return rc;
+    if ((rc = ensure(c, c->d_rays, 32))) return rc;
     if ((rc = ensure(c, c->d_overflow, 16))) return rc;
     c->capacity = cap;
     return RT_OK;
@@ -748,9 +749,10 @@ int rt_owned_pixels(uint32_t width, uint32_t height, uint32_t tile_size, uint32_
     return RT_OK;
 }
 
-int rt_profile_enable(rt_ctx* c, int on) {
+int rt_profile_enable(rt_ctx* c, int flags) {
     if (!c) return RT_ERR_INVALID;
-    c->profile = on != 0;
+    c->profile = (flags & 1) != 0;
+    c->count_visits = (flags & 2) != 0;
     return RT_OK;
 }
 
@@ -806,7 +808,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (n_owned && n_samples_total) {
         const uint64_t cap = std::min<uint64_t>(c->max_paths, n_owned * (uint64_t)n_samples_total);
         if ((rc = alloc_wavefront(c, std::max<uint64_t>(cap, 1024)))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 24, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
         uint32_t* counts = (uint32_t*)c->d_counts.p;
         const uint64_t pix_chunk = std::min<uint64_t>(n_owned, c->capacity);
@@ -828,7 +830,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 for (uint32_t b = 0; b < p->max_depth; b++) {
                     {
                         ScopedTimer tm(c, KS_TRACE);
-                        HIP_TRY(c, rtk::launch_trace(c->stream, c->stack_entries, c->has_groups, c->scene, path_state(c, which),
+                        HIP_TRY(c, rtk::launch_trace(c->stream, c->stack_entries, c->has_groups, c->count_visits, c->scene, path_state(c, which),
                                                      counts, which, n_bound, (float4*)c->d_hits.p,
                                                      (unsigned long long*)c->d_rays.p, (uint32_t*)c->d_overflow.p));
                     }
@@ -855,13 +857,15 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 }
             }
         }
-        HIP_TRY(c, hipMemcpyAsync(c->h_rays, c->d_rays.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_rays, c->d_rays.p, 24, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts + 2, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
     }
     if (!accum_dev) HIP_TRY(c, hipMemcpyAsync(accum_rgb, d_accum, accum_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_owned && n_samples_total) {
-        st.rays = *c->h_rays;
+        st.rays = c->h_rays[0];
+        st.node_visits = c->h_rays[1];
+        st.prim_tests = c->h_rays[2];
         if (c->h_counts[2]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     }
     if (c->profile) {

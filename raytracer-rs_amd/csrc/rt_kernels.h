@@ -29,8 +29,10 @@ constexpr int MAX_GRID = 256 * 8;  // 8 blocks per CU; larger batches grid-strid
 // stack_entries: 16, 32 or 64 (per-lane traversal stack in LDS); has_groups: scene holds instances/media
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const uint32_t* pixel_list, uint32_t npix_batch,
                          uint32_t sample0, uint32_t n_samples, PathState out, uint32_t* counts, float4* radiance);
-hipError_t launch_trace(hipStream_t s, int stack_entries, bool has_groups, const rtd::Scene& scene, PathState in,
-                        uint32_t* counts, uint32_t which, uint32_t n_bound, float4* hits,
+// rays_total: three 64-bit words: [0] += rays traced; with count_visits also [1] += inner nodes fetched,
+// [2] += primitive records tested (instrumented, slower kernel; used to price the algorithmic bytes per ray)
+hipError_t launch_trace(hipStream_t s, int stack_entries, bool has_groups, bool count_visits, const rtd::Scene& scene,
+                        PathState in, uint32_t* counts, uint32_t which, uint32_t n_bound, float4* hits,
                         unsigned long long* rays_total, uint32_t* overflow_flag);
 hipError_t launch_shade(hipStream_t s, const rtd::Scene& scene, const RenderConst& rc, PathState in, PathState out,
                         const float4* hits, uint32_t* counts, uint32_t which, uint32_t n_bound, float4* radiance);

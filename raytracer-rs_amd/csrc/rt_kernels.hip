@@ -240,9 +240,12 @@ DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tmin, float tbest, float& tn) {
 
 // Short-stack traversal of the two-level BVH.  stk points at this lane's column of the LDS stack;
 // consecutive entries are STRIDE words apart so that the 64 lanes of a wave hit 64 different banks.
-template <int STRIDE, int STACK, bool GROUPS>
+struct TraceCount {
+    uint32_t nodes, prims;  // inner nodes fetched, primitive records tested (instrumented builds only)
+};
+template <int STRIDE, int STACK, bool GROUPS, bool COUNT = false>
 DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
-                   uint32_t bounce, Hit& best, uint32_t* stk, uint32_t* overflow_flag) {
+                   uint32_t bounce, Hit& best, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
     best.t = tmax;
     best.prim = HIT_NONE;
     best.grp = -1;
@@ -260,6 +263,7 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
         if (type == REF_INNER) {
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
             float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (COUNT) cnt->nodes++;
             float tn0, tn1;
             bool h0 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, tn0);
             bool h1 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv, tmin, best.t, tn1);
@@ -288,8 +292,9 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
                 descend = true;
             }
         } else if (type == REF_PRIMS) {
-            uint32_t first = cur & 0x03FFFFFFu, cnt = ((cur >> 26) & 15u) + 1u;
-            for (uint32_t i = 0; i < cnt; i++) test_prim(S, first + i, o, d, a, time, tmin, grp, best);
+            uint32_t first = cur & 0x03FFFFFFu, n_leaf = ((cur >> 26) & 15u) + 1u;
+            for (uint32_t i = 0; i < n_leaf; i++) test_prim(S, first + i, o, d, a, time, tmin, grp, best);
+            if (COUNT) cnt->prims += n_leaf;
         } else if (GROUPS && type == REF_INSTANCE) {
             uint32_t g = cur & 0x3FFFFFFFu;
             const Group& G = S.groups[g];
@@ -332,7 +337,10 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
 surfaces_done:
     // media come after all surfaces, in creation order (the order of a Scene whose media were added last)
     if (GROUPS)
-        for (uint32_t m = 0; m < S.n_media; m++) test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
+        for (uint32_t m = 0; m < S.n_media; m++) {
+            test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
+            if (COUNT) cnt->prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);  // two boundary queries
+        }
 }
 
 // ---- hit record (hit_record.rs, shapes.rs) --------------------------------------
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, cons
     }
 }
 
-template <int STACK, bool GROUPS>
+template <int STACK, bool GROUPS, bool COUNT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in, uint32_t* counts, uint32_t which,
                                                        float4* __restrict__ hits, unsigned long long* rays_total,
                                                        uint32_t* overflow_flag) {
@@ -623,6 +631,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
         atomicAdd(rays_total, (unsigned long long)n);
     }
     uint32_t* stk = stack + threadIdx.x;
+    TraceCount tc{0u, 0u};
     for (uint32_t i = blockIdx.x * rtk::BLOCK + threadIdx.x; i < n; i += gridDim.x * rtk::BLOCK) {
         float4 ot = in.o_time[i];
         float4 ds = in.d_slot[i];
@@ -634,9 +643,13 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
             bounce = __float_as_uint(in.thr_meta[i].w) >> 24;
         }
         Hit h;
-        trace_ray<rtk::BLOCK, STACK, GROUPS>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, k0, k1,
-                                             bounce, h, stk, overflow_flag);
+        trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, k0,
+                                                    k1, bounce, h, stk, overflow_flag, &tc);
         hits[i] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), 0.0f);
+    }
+    if (COUNT) {  // rays_total[1] = inner nodes fetched, rays_total[2] = primitive records tested
+        if (tc.nodes) atomicAdd(rays_total + 1, (unsigned long long)tc.nodes);
+        if (tc.prims) atomicAdd(rays_total + 2, (unsigned long long)tc.prims);
     }
 }
 
@@ -836,27 +849,35 @@ hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const uint32_t* p
     return hipGetLastError();
 }
 
-template <int STACK>
+template <int STACK, bool COUNT>
 static void launch_trace_t(hipStream_t s, bool groups, int grid, const Scene& scene, PathState in, uint32_t* counts,
                            uint32_t which, float4* hits, unsigned long long* rays_total, uint32_t* overflow_flag) {
     if (groups)
-        hipLaunchKernelGGL((k_trace<STACK, true>), dim3(grid), dim3(BLOCK), 0, s, scene, in, counts, which, hits, rays_total,
-                           overflow_flag);
+        hipLaunchKernelGGL((k_trace<STACK, true, COUNT>), dim3(grid), dim3(BLOCK), 0, s, scene, in, counts, which, hits,
+                           rays_total, overflow_flag);
     else
-        hipLaunchKernelGGL((k_trace<STACK, false>), dim3(grid), dim3(BLOCK), 0, s, scene, in, counts, which, hits,
+        hipLaunchKernelGGL((k_trace<STACK, false, COUNT>), dim3(grid), dim3(BLOCK), 0, s, scene, in, counts, which, hits,
                            rays_total, overflow_flag);
 }
 
-hipError_t launch_trace(hipStream_t s, int stack_entries, bool has_groups, const Scene& scene, PathState in,
-                        uint32_t* counts, uint32_t which, uint32_t n_bound, float4* hits, unsigned long long* rays_total,
-                        uint32_t* overflow_flag) {
+hipError_t launch_trace(hipStream_t s, int stack_entries, bool has_groups, bool count_visits, const Scene& scene,
+                        PathState in, uint32_t* counts, uint32_t which, uint32_t n_bound, float4* hits,
+                        unsigned long long* rays_total, uint32_t* overflow_flag) {
     int grid = grid_for(n_bound);
+#define RT_TRACE_DISPATCH(N)                                                                                      \
+    do {                                                                                                          \
+        if (count_visits)                                                                                         \
+            launch_trace_t<N, true>(s, has_groups, grid, scene, in, counts, which, hits, rays_total, overflow_flag);  \
+        else                                                                                                      \
+            launch_trace_t<N, false>(s, has_groups, grid, scene, in, counts, which, hits, rays_total, overflow_flag); \
+    } while (0)
     if (stack_entries <= 16)
-        launch_trace_t<16>(s, has_groups, grid, scene, in, counts, which, hits, rays_total, overflow_flag);
+        RT_TRACE_DISPATCH(16);
     else if (stack_entries <= 32)
-        launch_trace_t<32>(s, has_groups, grid, scene, in, counts, which, hits, rays_total, overflow_flag);
+        RT_TRACE_DISPATCH(32);
     else
-        launch_trace_t<64>(s, has_groups, grid, scene, in, counts, which, hits, rays_total, overflow_flag);
+        RT_TRACE_DISPATCH(64);
+#undef RT_TRACE_DISPATCH
     return hipGetLastError();
 }
 

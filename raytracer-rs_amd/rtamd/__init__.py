@@ -60,7 +60,7 @@ class rt_render_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("batches", C.c_uint32), ("bounce_launches", C.c_uint32),
                 ("render_ms", C.c_double), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
                 ("raygen_ms", C.c_double), ("accumulate_ms", C.c_double), ("trace_launches", C.c_uint64),
-                ("shade_launches", C.c_uint64)]
+                ("shade_launches", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -244,8 +244,8 @@ class Context:
     def synchronize(self):
         self._check(self.L.rt_ctx_synchronize(self.h))
 
-    def profile(self, on=True):
-        self._check(self.L.rt_profile_enable(self.h, 1 if on else 0))
+    def profile(self, events=True, count_visits=False):
+        self._check(self.L.rt_profile_enable(self.h, (1 if events else 0) | (2 if count_visits else 0)))
 
     # ---- scenes ------------------------------------------------------------------
     def load_scene(self, name, seed=1, n_synth=0, earthmap=None):
