@@ -29,6 +29,7 @@ sys.path.insert(0, str(ROOT / "raytracer-rs_amd"))
 import torch  # noqa: E402
 
 import rtamd  # noqa: E402
+from rtamd.dist import TileGather  # noqa: E402
 
 # BASELINE.json configs: name -> (frames, width, aspect, spp)
 WORKLOADS = {
@@ -66,35 +67,19 @@ class Frame:
         self.cam = self.ctx.preset_camera(aspect)
         self.accum = torch.zeros((self.h, self.w, 3), dtype=torch.float32, device=f"cuda:{device}")
         self.tile = tile
-        if world > 1:
-            owned = [rtamd.owned_pixels(self.w, self.h, tile, r, world) for r in range(world)]
-            self.pad = max(len(o) for o in owned)
-            dev = self.accum.device
-            self.my_idx = torch.from_numpy(owned[rank].astype(np.int64)).to(dev)
-            # destination pixel of every gathered slot; padding slots point one past the frame
-            dst = np.full((world, self.pad), self.w * self.h, dtype=np.int64)
-            for r, o in enumerate(owned):
-                dst[r, : len(o)] = o
-            self.dst_idx = torch.from_numpy(dst.reshape(-1)).to(dev)
-            self.packed = torch.zeros((self.pad, 3), dtype=torch.float32, device=dev)
-            self.gathered = torch.empty((world * self.pad, 3), dtype=torch.float32, device=dev)
-            self.full = torch.zeros((self.h * self.w + 1, 3), dtype=torch.float32, device=dev)
+        self.gather = TileGather(self.w, self.h, rank, world, self.accum.device, tile) if world > 1 else None
 
     def render(self, spp=None):
         self.accum.zero_()
         _, st = self.ctx.render(self.w, self.h, self.cam, spp or self.spp, depth=MAX_DEPTH, seed=1, accum=self.accum,
                                 tile_size=self.tile, rank=self.rank, nranks=self.world)
-        if self.world > 1:
+        if self.gather is not None:
             # framebuffer exchange: every rank owns disjoint tiles -> one all_gather of the packed tiles
-            self.packed[: self.my_idx.numel()] = self.accum.view(-1, 3)[self.my_idx]
-            torch.distributed.all_gather_into_tensor(self.gathered, self.packed)
-            self.full.index_copy_(0, self.dst_idx, self.gathered)
+            self.frame = self.gather.gather(self.accum)
         return st
 
     def image(self):
-        if self.world > 1:
-            return self.full[:-1].view(self.h, self.w, 3)
-        return self.accum
+        return self.frame if self.gather is not None else self.accum
 
 
 def trace_bytes_per_ray(info, nodes_per_ray, prims_per_ray):

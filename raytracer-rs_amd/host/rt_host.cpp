@@ -295,6 +295,42 @@ int rth_scene_upload(void* h, rt_ctx* ctx, char* err, int errlen) {
     }
 }
 
+// Flattens without touching a GPU and reports what the C ABI would receive (host-logic checks):
+// info[0] primitives, [1] instances (TransformedObject count), [2] media, [3] top-level objects,
+// [4] spheres, [5] rects, [6] groups, [7] materials, [8] textures, [9] perlin tables, [10] images,
+// [11] moving spheres.  ids_ok is set to 1 when the primitive ids are exactly 0..n-1.
+int rth_scene_flatten_counts(void* h, int64_t info[12], int* ids_ok, char* err, int errlen) {
+    Built* b = static_cast<Built*>(h);
+    if (!b) return RT_ERR_INVALID;
+    try {
+        FlatScene fs;
+        b->world.flatten(fs, 0);
+        info[0] = fs.next_id;
+        info[1] = fs.n_instances;
+        info[2] = fs.n_media;
+        info[3] = (int64_t)b->world.shapes.size();
+        info[4] = (int64_t)fs.sph_id.size();
+        info[5] = (int64_t)fs.rect_id.size();
+        info[6] = (int64_t)fs.groups.size();
+        info[7] = (int64_t)fs.mats.size();
+        info[8] = (int64_t)fs.texs.size();
+        info[9] = (int64_t)fs.perlin.size();
+        info[10] = (int64_t)fs.images.size();
+        int64_t moving = 0;
+        for (uint8_t m : fs.sph_moving) moving += m;
+        info[11] = moving;
+        std::vector<uint8_t> seen(fs.next_id, 0);
+        bool ok = fs.sph_id.size() + fs.rect_id.size() == fs.next_id;
+        for (uint32_t id : fs.sph_id) ok = ok && id < fs.next_id && !seen[id]++;
+        for (uint32_t id : fs.rect_id) ok = ok && id < fs.next_id && !seen[id]++;
+        if (ids_ok) *ids_ok = ok ? 1 : 0;
+        return RT_OK;
+    } catch (const std::exception& e) {
+        copy_err(err, errlen, e.what());
+        return RT_ERR_UNSUPPORTED;
+    }
+}
+
 // cam[0..2] origin, [3..5] target, [6] vfov in degrees, [7] aperture, [8..10] background
 void rth_scene_preset(void* h, float cam[11]) {
     const Preset& p = static_cast<Built*>(h)->preset;

@@ -153,6 +153,8 @@ def host():
     H.rth_scene_destroy.restype = None
     H.rth_scene_upload.argtypes = [vp, vp, C.c_char_p, C.c_int]
     H.rth_scene_upload.restype = C.c_int
+    H.rth_scene_flatten_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    H.rth_scene_flatten_counts.restype = C.c_int
     H.rth_scene_preset.argtypes = [vp, C.POINTER(C.c_float)]
     H.rth_scene_preset.restype = None
     H.rth_scene_counts.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -199,6 +201,29 @@ def owned_pixels(width, height, tile_size=32, rank=0, nranks=1):
     out = np.empty(n.value, dtype=np.uint32)
     core().rt_owned_pixels(width, height, tile_size, rank, nranks, _ptr(out), n.value, C.byref(n))
     return out
+
+
+def flatten_counts(name, seed=1, n_synth=0, earthmap=None):
+    """Build a named scene with the C++ mirror API and flatten it on the host (no GPU needed).
+    Returns a dict of what would go through rt_scene_set_*."""
+    H = host()
+    err = C.create_string_buffer(512)
+    h = H.rth_scene_build(name.encode(), seed, str(earthmap or EARTHMAP).encode(), n_synth, err, len(err))
+    if not h:
+        raise RtError(-1, err.value.decode())
+    try:
+        info = (C.c_int64 * 12)()
+        ok = C.c_int(0)
+        rc = H.rth_scene_flatten_counts(C.c_void_p(h), info, C.byref(ok), err, len(err))
+        if rc != RT_OK:
+            raise RtError(rc, err.value.decode())
+        keys = ("prims", "instances", "media", "top_level", "spheres", "rects", "groups", "materials", "textures",
+                "perlin_tables", "images", "moving_spheres")
+        out = dict(zip(keys, (int(x) for x in info)))
+        out["ids_ok"] = bool(ok.value)
+        return out
+    finally:
+        H.rth_scene_destroy(C.c_void_p(h))
 
 
 class Context:
@@ -274,6 +299,59 @@ class Context:
         cnt = (C.c_int64 * 4)()
         H.rth_scene_counts(self.scene_handle, cnt)
         self.n_prims, self.n_instances, self.n_media, self.n_top = (int(x) for x in cnt)
+        return self.info()
+
+    def set_scene(self, spheres=None, rects=None, groups=(), materials=(), textures=(), perlin=None, images=None,
+                  shutter=(0.0, 1.0)):
+        """Upload a scene given directly as the flat arrays of rt_scene_set_* (what a foreign caller of the C
+        ABI sends) and commit it.
+
+        spheres: dict c0r (n,4) [, c1 (n,3), t01 (n,2), moving (n,)], mat (n,), id (n,) [, group (n,)]
+        rects:   dict axis (n,), k (n,), bounds (n,4), mat (n,), id (n,) [, group (n,)]
+        groups / materials / textures: sequences of rt_group / rt_material / rt_texture
+        perlin:  {table: (vec (256,3) f32, perm (3,256) i32)} ; images: {table: (h,w,3) u8}
+        """
+        L = self.L
+        keep = []  # keep converted arrays alive across the calls
+
+        def arr(d, k, dt, shape=None):
+            if d is None or d.get(k) is None:
+                return None
+            a = np.ascontiguousarray(d[k], dtype=dt)
+            if shape is not None:
+                a = a.reshape(shape)
+            keep.append(a)
+            return a
+
+        def carr(seq, ctype):
+            a = (ctype * max(len(seq), 1))(*seq)
+            keep.append(a)
+            return a
+
+        self._check(L.rt_scene_clear(self.h))
+        self._check(L.rt_scene_set_textures(self.h, len(textures), carr(list(textures), rt_texture)))
+        self._check(L.rt_scene_set_materials(self.h, len(materials), carr(list(materials), rt_material)))
+        for t, (vec, perm) in (perlin or {}).items():
+            v = np.ascontiguousarray(vec, np.float32).reshape(256, 3)
+            p = np.ascontiguousarray(perm, np.int32).reshape(3, 256)
+            self._check(L.rt_scene_set_perlin(self.h, t, _ptr(v), _ptr(p)))
+        for t, img in (images or {}).items():
+            im = np.ascontiguousarray(img, np.uint8)
+            self._check(L.rt_scene_set_image(self.h, t, im.shape[1], im.shape[0], _ptr(im)))
+        self._check(L.rt_scene_set_groups(self.h, len(groups), carr(list(groups), rt_group)))
+        n = 0 if spheres is None else len(spheres["id"])
+        self._check(L.rt_scene_set_spheres(
+            self.h, n, _ptr(arr(spheres, "c0r", np.float32, (n, 4))), _ptr(arr(spheres, "c1", np.float32, (n, 3))),
+            _ptr(arr(spheres, "t01", np.float32, (n, 2))), _ptr(arr(spheres, "moving", np.uint8)),
+            _ptr(arr(spheres, "mat", np.uint32)), _ptr(arr(spheres, "id", np.uint32)), _ptr(arr(spheres, "group", np.uint32))))
+        n = 0 if rects is None else len(rects["id"])
+        self._check(L.rt_scene_set_rects(
+            self.h, n, _ptr(arr(rects, "axis", np.uint8)), _ptr(arr(rects, "k", np.float32)),
+            _ptr(arr(rects, "bounds", np.float32, (n, 4))), _ptr(arr(rects, "mat", np.uint32)),
+            _ptr(arr(rects, "id", np.uint32)), _ptr(arr(rects, "group", np.uint32))))
+        self._check(L.rt_scene_commit(self.h, shutter[0], shutter[1]))
+        self.scene_name = "<raw>"
+        self.background = np.zeros(3, np.float32)
         return self.info()
 
     def preset_camera(self, aspect):

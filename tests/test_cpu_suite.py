@@ -1,0 +1,225 @@
+"""CPU suite (no GPU): oracle against the committed golden vectors, the C ABI surface, host logic
+(scene flattening through the C++ mirror API, tile ownership, BVH builder invariants) and the
+multi-rank framebuffer gather over gloo."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import orc
+import rtamd
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden"
+RAY_SCENES = ["random_world", "earth", "simple_light", "cornell_box", "cornell_smoke", "final_scene"]
+IMAGE_SCENES = ["random_world", "two_spheres", "two_perlin_spheres", "earth", "simple_light", "cornell_box",
+                "cornell_smoke", "final_scene"]
+
+
+# ---- oracle vs golden vectors ------------------------------------------------------------------
+@pytest.mark.parametrize("name", RAY_SCENES)
+def test_oracle_reproduces_golden_ray_batches(name):
+    g = np.load(GOLDEN / f"rays_{name}.npz")
+    sc = orc.Scene(name, seed=1)
+    for mode in (0, 1):
+        out = sc.intersect(g["rays"], seed=3, mode=mode)
+        assert np.array_equal(out["prim"], g["prim"]) and np.array_equal(out["inst"], g["inst"])
+        assert np.array_equal(out["t"], g["t"]) and np.array_equal(out["front"], g["front"])
+        assert np.array_equal(out["normal"], g["normal"]) and np.array_equal(out["point"], g["point"])
+        assert np.array_equal(out["uv"], g["uv"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", IMAGE_SCENES)
+def test_oracle_reproduces_golden_images(name):
+    g = np.load(GOLDEN / f"image_{name}.npz")
+    sc = orc.Scene(name, seed=1)
+    h, w, _ = g["sum_rgb"].shape
+    img, rays = sc.render(w, h, 1.0, int(g["spp"]), depth=50, seed=1, mode=1)
+    assert rays == int(g["rays"])
+    assert np.array_equal(img, g["sum_rgb"])
+    # the linear Scene path renders the same image: same closest hits, same RNG streams
+    img0, rays0 = sc.render(w, h, 1.0, int(g["spp"]), depth=50, seed=1, mode=0)
+    assert rays0 == rays and np.array_equal(img0, img)
+
+
+def test_oracle_render_is_partition_and_sample_split_invariant():
+    sc = orc.Scene("cornell_smoke", seed=1)
+    w = h = 24
+    full, rays = sc.render(w, h, 1.0, 6, seed=2, mode=1)
+    parts = np.zeros_like(full)
+    r2 = 0
+    for tile in [(0, 0, 12, 24), (12, 0, 24, 10), (12, 10, 24, 24)]:
+        _, r = sc.render(w, h, 1.0, 6, seed=2, mode=1, tile=tile, sum_rgb=parts)
+        r2 += r
+    assert r2 == rays and np.array_equal(parts, full)
+    split = np.zeros_like(full)
+    sc.render(w, h, 1.0, 2, seed=2, mode=1, s0=0, sum_rgb=split)
+    sc.render(w, h, 1.0, 4, seed=2, mode=1, s0=2, sum_rgb=split)
+    assert np.array_equal(split, full)
+
+
+def test_earthmap_fixture():
+    import hashlib
+    img = orc.earthmap()
+    assert img.shape == (512, 1024, 3)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == "a8cdc92a168d554ddc693785d31f5e251063724f44099571d7fbce3b43d44c45"
+
+
+# ---- C ABI surface (no compute calls) -------------------------------------------------------------
+def declared_functions():
+    text = (ROOT / "include" / "rtamd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 20
+    assert sorted(rtamd.ABI_SYMBOLS) == names, "rtamd.ABI_SYMBOLS and include/rtamd.h disagree"
+    lib = C.CDLL(str(rtamd.LIB_DIR / "librtamd.so"))
+    for n in names:
+        assert hasattr(lib, n), f"librtamd.so does not export {n}"
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """The header compiles as plain C and the ctypes mirrors have the sizes the C compiler gives."""
+    names = ["rt_camera", "rt_material", "rt_texture", "rt_group", "rt_render_params", "rt_render_stats", "rt_scene_info"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rtamd.h"\nint main(void){' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-o", str(exe), str(src)], check=True)
+    sizes = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for n in names:
+        assert C.sizeof(getattr(rtamd, n)) == int(sizes[n]), n
+    assert int(sizes["rt_material"]) == 32 and int(sizes["rt_texture"]) == 32 and int(sizes["rt_camera"]) == 96
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(rtamd.RtError) as e:
+        rtamd.Context(0)
+    assert e.value.code == -5  # RT_ERR_NO_DEVICE
+    assert rtamd.core().rt_scene_clear(None) == -1  # RT_ERR_INVALID on a null context
+    assert rtamd.core().rt_last_error(None) == b"null context"
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under raytracer-rs_amd/ or include/ may name it."""
+    for path in list((ROOT / "raytracer-rs_amd").rglob("*")) + list((ROOT / "include").rglob("*")):
+        if path.is_file() and path.suffix in (".py", ".cpp", ".hpp", ".h", ".hip", "") and "lib" not in path.parts and "build" not in path.parts:
+            text = path.read_text(errors="ignore")
+            assert "liboracle" not in text and "rt_oracle" not in text and "import orc" not in text, path
+
+
+# ---- host logic ---------------------------------------------------------------------------------------
+def test_owned_pixels_partition_the_frame():
+    w, h, ts = 100, 70, 32
+    for world in (1, 2, 3, 8):
+        seen = np.zeros(w * h, np.int32)
+        counts = []
+        for r in range(world):
+            px = rtamd.owned_pixels(w, h, ts, r, world)
+            seen[px] += 1
+            counts.append(len(px))
+            tiles = (px // w // ts) * ((w + ts - 1) // ts) + (px % w) // ts
+            assert np.all(tiles % world == r)
+        assert np.all(seen == 1)
+        assert sum(counts) == w * h
+    # tile-major order: the first tile's rows come first
+    px = rtamd.owned_pixels(w, h, ts, 0, 1)
+    assert px[:3].tolist() == [0, 1, 2] and px[32] == w and px[32 * 32] == 32
+
+
+@pytest.mark.parametrize("name", rtamd.SCENES[:-1])
+def test_flattened_scene_matches_oracle_inventory(name):
+    sc = orc.Scene(name, seed=4)
+    fc = rtamd.flatten_counts(name, seed=4)
+    assert fc["ids_ok"]
+    assert (fc["prims"], fc["instances"], fc["media"], fc["top_level"]) == (sc.n_prims, sc.n_instances, sc.n_media, sc.n_top)
+    assert fc["spheres"] + fc["rects"] == fc["prims"]
+
+
+def test_flattened_scene_details():
+    fc = rtamd.flatten_counts("cornell_smoke")
+    assert fc["rects"] == 18 and fc["groups"] == 2 and fc["spheres"] == 0
+    fc = rtamd.flatten_counts("final_scene")
+    assert fc["rects"] == 2401 and fc["spheres"] == 1008 and fc["groups"] == 3 and fc["moving_spheres"] == 1
+    assert fc["perlin_tables"] == 1 and fc["images"] == 1
+    fc = rtamd.flatten_counts("random_world", seed=9)
+    sc = orc.Scene("random_world", seed=9)
+    assert fc["prims"] == sc.n_prims and 0.6 * fc["prims"] < fc["moving_spheres"] < 0.95 * fc["prims"]
+    fc = rtamd.flatten_counts("synth_spheres", n_synth=1000)
+    assert fc["spheres"] == 1001 and fc["materials"] == 1001
+    with pytest.raises(rtamd.RtError):
+        rtamd.flatten_counts("no_such_scene")
+    with pytest.raises(rtamd.RtError):
+        rtamd.flatten_counts("earth", earthmap="/nonexistent/earthmap.ppm")  # texture.rs:91 panics; here an error
+
+
+def test_camera_mirror_matches_oracle():
+    for name in ("random_world", "cornell_box", "final_scene", "simple_light"):
+        sc = orc.Scene(name)
+        for aspect in (1.0, 16.0 / 9.0):
+            want = orc.camera_new(sc.cam_origin, sc.cam_target, (0, 1, 0), np.float32(sc.vfov_deg) * np.float32(np.pi) / np.float32(180),
+                                  aspect, sc.aperture, 10.0, 0.0, 1.0)
+            got = rtamd.camera_new(sc.cam_origin, sc.cam_target, (0, 1, 0), np.float32(sc.vfov_deg) * np.float32(np.pi) / np.float32(180),
+                                   aspect, sc.aperture, 10.0, 0.0, 1.0).as_array()
+            assert np.array_equal(got, want)
+
+
+@pytest.fixture(scope="module")
+def bvh_check(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("bvh") / "bvh_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), str(ROOT / "tests" / "cpp" / "bvh_check.cpp"),
+                    str(ROOT / "raytracer-rs_amd" / "csrc" / "rt_bvh.cpp")], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("n,seed,leaf", [(1, 1, 4), (2, 1, 4), (7, 2, 4), (1000, 3, 1), (20001, 5, 4), (50000, 7, 16)])
+def test_bvh_builder_invariants(bvh_check, n, seed, leaf):
+    r = subprocess.run([str(bvh_check), str(n), str(seed), str(leaf)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), r.stdout[-500:]
+
+
+# ---- N > 1: framebuffer gather over gloo, world size 2 -----------------------------------------------
+GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["RT_PKG"])
+import numpy as np, torch, torch.distributed as dist
+import rtamd
+from rtamd.dist import TileGather
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+w, h, ts = 70, 45, 16
+frame = torch.arange(w * h * 3, dtype=torch.float32).reshape(h, w, 3) * 0.5 + 1.0   # what a 1-rank render would hold
+mine = torch.zeros_like(frame)
+idx = torch.from_numpy(rtamd.owned_pixels(w, h, ts, rank, world).astype(np.int64))
+mine.view(-1, 3)[idx] = frame.view(-1, 3)[idx]                                          # this rank rendered only its tiles
+g = TileGather(w, h, rank, world, "cpu", ts)
+full = g.gather(mine)
+assert torch.equal(full, frame), "gathered frame differs from the single-rank frame"
+full2 = g.gather(mine)                                                                  # reusable across frames
+assert torch.equal(full2, frame)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_tile_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER)
+    env = dict(os.environ, RT_PKG=str(ROOT / "raytracer-rs_amd"), MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o[-2000:]

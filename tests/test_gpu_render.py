@@ -1,0 +1,292 @@
+"""GPU parity tests of the render path (all through the C ABI): known answers on raw scenes, golden
+vectors, image parity with the CPU oracle at equal spp, and size-independent properties at
+BASELINE.json's full frame sizes.
+
+Stated tolerances
+  * hit ids bit-exact, t / normal within 1e-5 relative (north star);
+  * images: the GPU follows the oracle's arithmetic and RNG streams, so almost every pixel agrees to
+    rounding.  What differs are libm-vs-device transcendentals (sin, acos, atan2, pow, f64 log) and the
+    order of the throughput product, which can flip a rare path at a checker edge, a texel boundary or a
+    Schlick test.  Bar: per-sample RMSE <= 5e-3 (Monte Carlo noise at these sample counts is > 1e-1) and
+    at least 99 % of the pixels within 1e-4 of the oracle.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import orc
+import rtamd
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = orc.ROOT / "tests" / "golden"
+ALL_SCENES = ["random_world", "two_spheres", "two_perlin_spheres", "earth", "simple_light", "cornell_box",
+              "cornell_smoke", "final_scene"]
+INF = float("inf")
+
+
+def assert_images_close(gpu_sum, ref_sum, spp, name):
+    d = (gpu_sum.astype(np.float64) - ref_sum.astype(np.float64)) / spp
+    rmse = math.sqrt(float(np.mean(d * d)))
+    close = np.abs(d).max(axis=2) <= 1e-4
+    assert np.isfinite(gpu_sum).all(), name
+    assert rmse <= 5e-3, f"{name}: per-sample RMSE {rmse}"
+    assert close.mean() >= 0.99, f"{name}: only {close.mean():.4f} of the pixels within 1e-4"
+    return rmse, close.mean()
+
+
+# ---- known answers on raw scenes sent through rt_scene_set_* ----------------------------------------
+def solid_lambertian():
+    t = rtamd.rt_texture(kind=0, color=(C.c_float * 3)(0.5, 0.5, 0.5))
+    m = rtamd.rt_material(kind=0, tex=0)
+    return [m], [t]
+
+
+def one_ray(o, d, time=0.0):
+    return np.array([[o[0]], [o[1]], [o[2]], [d[0]], [d[1]], [d[2]], [time]], np.float32)
+
+
+def test_kat_sphere_through_raw_abi(gpu_ctx):
+    mats, texs = solid_lambertian()
+    gpu_ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0]), materials=mats, textures=texs)
+    r = gpu_ctx.intersect(one_ray((0, 0, -5), (0, 0, 1)))  # K1
+    assert r["prim"][0] == 0 and r["t"][0] == 4.0 and r["front"][0] == 1
+    assert r["normal"][0].tolist() == [0.0, 0.0, -1.0] and r["point"][0].tolist() == [0.0, 0.0, -1.0]
+    assert r["uv"][0] == pytest.approx([0.75, 0.5], abs=1e-6)
+    r = gpu_ctx.intersect(one_ray((0, 0, 0), (0, 0, 1)))  # K2: from inside
+    assert r["t"][0] == 1.0 and r["front"][0] == 0 and r["normal"][0].tolist() == [0.0, 0.0, -1.0]
+    r = gpu_ctx.intersect(one_ray((0, 0, -5), (0, 0, 2)))  # K3
+    assert r["t"][0] == 2.0
+    r = gpu_ctx.intersect(one_ray((0, 0, -5), (0, 0, 1)), tmax=4.0)  # inclusive bound
+    assert r["prim"][0] == 0
+    r = gpu_ctx.intersect(one_ray((0, 0, -5), (0, 0, 1)), tmax=3.9)
+    assert r["prim"][0] == -1 and np.isinf(r["t"][0])
+    r = gpu_ctx.intersect(one_ray((0, 3, -5), (0, 0, 1)))
+    assert r["prim"][0] == -1
+
+
+def test_kat_rects_moving_sphere_and_tie_rule(gpu_ctx):
+    mats, texs = solid_lambertian()
+    # K5: the Cornell light (main.rs:187); K6: moving sphere at mid shutter
+    gpu_ctx.set_scene(
+        rects=dict(axis=[1, 2], k=[554.0, 3.0], bounds=[[213, 227, 343, 332], [0, 10, 5, 20]], mat=[0, 0], id=[0, 1]),
+        spheres=dict(c0r=[[100, 0, 0, 1]], c1=[[100, 2, 0]], t01=[[0, 1]], moving=[1], mat=[0], id=[2]),
+        materials=mats, textures=texs)
+    r = gpu_ctx.intersect(one_ray((278, 0, 279), (0, 1, 0)))
+    assert r["prim"][0] == 0 and r["t"][0] == 554.0 and r["front"][0] == 0 and r["normal"][0].tolist() == [0.0, -1.0, 0.0]
+    assert r["uv"][0] == pytest.approx([(278 - 213) / 130, (279 - 227) / 105], rel=1e-6)
+    r = gpu_ctx.intersect(one_ray((0, 2, 15), (1, 0, 0)))
+    assert r["prim"][0] == 1 and r["t"][0] == 3.0 and r["normal"][0].tolist() == [-1.0, 0.0, 0.0]
+    r = gpu_ctx.intersect(one_ray((100, 1, -5), (0, 0, 1), 0.5))
+    assert r["prim"][0] == 2 and r["t"][0] == 4.0
+    # exact tie: two coincident rects, the later id wins (scene.rs:32-38)
+    gpu_ctx.set_scene(rects=dict(axis=[0, 0, 0], k=[2.0, 2.0, 2.0], bounds=[[0, 0, 1, 1]] * 3, mat=[0, 0, 0], id=[0, 1, 2]),
+                      materials=mats, textures=texs)
+    r = gpu_ctx.intersect(one_ray((0.5, 0.5, 0), (0, 0, 1)))
+    assert r["prim"][0] == 2 and r["t"][0] == 2.0
+
+
+def box_rects(w, h, d, first_id, group):
+    """Box2::full_box side order (shapes.rs:459-466)."""
+    axis = [0, 0, 1, 1, 2, 2]
+    k = [0.0, d, 0.0, h, 0.0, w]
+    b = [[0, 0, w, h], [0, 0, w, h], [0, 0, w, d], [0, 0, w, d], [0, 0, h, d], [0, 0, h, d]]
+    return dict(axis=axis, k=k, bounds=b, mat=[0] * 6, id=list(range(first_id, first_id + 6)), group=[group] * 6)
+
+
+def test_kat_instance_and_medium(gpu_ctx):
+    mats, texs = solid_lambertian()
+    mats.append(rtamd.rt_material(kind=4, tex=0))
+    g = rtamd.rt_group(kind=1, has_xform=1)
+    g.m = (C.c_float * 12)(1, 0, 0, 10, 0, 1, 0, 0, 0, 0, 1, 0)      # translate x by 10
+    g.minv = (C.c_float * 12)(1, 0, 0, -10, 0, 1, 0, 0, 0, 0, 1, 0)
+    gpu_ctx.set_scene(rects=box_rects(2, 2, 2, 0, 1), groups=[g], materials=mats, textures=texs)
+    r = gpu_ctx.intersect(one_ray((11, 1, -5), (0, 0, 1)))  # K7
+    assert r["prim"][0] == 0 and r["inst"][0] == 0 and r["t"][0] == 5.0 and r["point"][0].tolist() == [11.0, 1.0, 0.0]
+    assert r["front"][0] == 1 and r["normal"][0].tolist() == [0.0, 0.0, -1.0]
+    r = gpu_ctx.intersect(one_ray((11, 1, 1), (0, 0, 1)))  # from inside: front_face still true (shapes.rs:75-86)
+    assert r["prim"][0] == 1 and r["t"][0] == 1.0 and r["front"][0] == 1 and r["normal"][0].tolist() == [0.0, 0.0, -1.0]
+    # K13: medium over a sphere; xi comes from stream (seed, pixel = ray index, sample 0), bounce 0, medium 0
+    density = 0.5
+    m = rtamd.rt_group(kind=2, has_xform=0, neg_inv_density=-1.0 / density, mat=1)
+    gpu_ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 2]], mat=[0], id=[0], group=[1]), groups=[m], materials=mats, textures=texs)
+    rays = np.repeat(one_ray((0, 0, -5), (0, 0, 1)), 64, axis=1)
+    r = gpu_ctx.intersect(rays, seed=11)
+    for i in range(64):
+        xi = orc.lib().orc_rng_medium_xi(11, i, 0, 0, 0)
+        hit = -math.log(xi) / density
+        if hit > 4.0:
+            assert r["prim"][i] == -1
+        else:
+            assert r["prim"][i] == -2 and r["t"][i] == pytest.approx(3.0 + hit, rel=1e-6)
+            assert r["normal"][i].tolist() == [1.0, 0.0, 0.0] and r["front"][i] == 1
+    assert (r["prim"] == -2).sum() > 40
+
+
+def test_error_paths(gpu_ctx):
+    ctx = rtamd.Context(0)
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.intersect(one_ray((0, 0, 0), (0, 0, 1)))
+    assert e.value.code == -4  # RT_ERR_NOT_COMMITTED
+    mats, texs = solid_lambertian()
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[5], id=[0]), materials=mats, textures=texs)
+    assert e.value.code == -1 and "material" in str(e.value)
+    ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0]), materials=mats, textures=texs)
+    cam = rtamd.camera_new((0, 0, -5), (0, 0, 0), (0, 1, 0), 0.5, 1.0, 0.0, 10.0, 0.0, 1.0)
+    with pytest.raises(rtamd.RtError):
+        ctx.render(1, 1, cam, 1)  # width - 1 divides the jitter (main.rs:471)
+    with pytest.raises(rtamd.RtError):
+        ctx.render(8, 8, cam, 1, depth=0)
+    ctx.close()
+
+
+# ---- golden vectors -------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["random_world", "earth", "simple_light", "cornell_box", "cornell_smoke", "final_scene"])
+def test_golden_ray_batches(gpu_ctx, name):
+    g = np.load(GOLDEN / f"rays_{name}.npz")
+    gpu_ctx.load_scene(name, seed=1)
+    out = gpu_ctx.intersect(g["rays"], seed=3)
+    assert np.array_equal(out["prim"], g["prim"]) and np.array_equal(out["inst"], g["inst"])
+    hit = g["prim"] != -1
+    assert np.all(np.abs(out["t"][hit] - g["t"][hit]) <= 1e-5 * np.abs(g["t"][hit]))
+    assert np.abs(out["normal"] - g["normal"]).max() <= 1e-5
+    assert np.array_equal(out["front"], g["front"])
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_golden_images(gpu_ctx, name):
+    g = np.load(GOLDEN / f"image_{name}.npz")
+    h, w, _ = g["sum_rgb"].shape
+    spp = int(g["spp"])
+    gpu_ctx.load_scene(name, seed=1)
+    img, st = gpu_ctx.render(w, h, gpu_ctx.preset_camera(1.0), spp, depth=50, seed=1)
+    assert abs(st["rays"] - int(g["rays"])) <= max(2, 0.002 * int(g["rays"]))
+    assert st["paths"] == w * h * spp
+    assert_images_close(img, g["sum_rgb"], spp, name)
+
+
+# ---- image parity with the oracle at equal spp -------------------------------------------------------
+@pytest.mark.parametrize("name,aspect", [("random_world", 16 / 9), ("two_spheres", 16 / 9), ("two_perlin_spheres", 16 / 9),
+                                         ("earth", 16 / 9), ("simple_light", 16 / 9), ("cornell_box", 1.0),
+                                         ("cornell_smoke", 1.0), ("final_scene", 1.0)])
+def test_image_matches_oracle_at_equal_spp(gpu_ctx, name, aspect):
+    w, spp = 160, 8
+    h = rtamd.image_height(w, aspect)
+    osc = orc.Scene(name, seed=2)
+    gpu_ctx.load_scene(name, seed=2)
+    ref, rays = osc.render(w, h, aspect, spp, depth=50, seed=5, mode=1)
+    img, st = gpu_ctx.render(w, h, gpu_ctx.preset_camera(aspect), spp, depth=50, seed=5)
+    assert abs(st["rays"] - rays) <= 0.002 * rays
+    assert_images_close(img, ref, spp, name)
+    # quantised output (main.rs:307-313): device resolve == oracle resolve on the same sums, and the two
+    # images differ on a vanishing share of the bytes
+    q_gpu = gpu_ctx.resolve_u8(img, spp)
+    assert np.array_equal(q_gpu, orc.resolve_u8(img, spp))
+    assert (q_gpu != orc.resolve_u8(ref, spp)).mean() <= 0.01
+
+
+def test_c1_config_full_size_against_oracle(gpu_ctx):
+    """BASELINE configs[0]: random world 400x225, 10 spp, depth 50 -- the whole frame against the oracle."""
+    w, aspect, spp = 400, 16 / 9, 10
+    h = rtamd.image_height(w, aspect)
+    assert h == 225
+    osc = orc.Scene("random_world", seed=1)
+    gpu_ctx.load_scene("random_world", seed=1)
+    ref, rays = osc.render(w, h, aspect, spp, depth=50, seed=1, mode=1)
+    img, st = gpu_ctx.render(w, h, gpu_ctx.preset_camera(aspect), spp, depth=50, seed=1)
+    assert st["paths"] == 900000 and abs(st["rays"] - rays) <= 0.001 * rays
+    assert_images_close(img, ref, spp, "c1")
+
+
+def test_resolve_u8_edge_values(gpu_ctx):
+    vals = np.array([0.0, 0.5, 1.0, 0.999, np.nan, -1.0, 2.0, 1 / 256, np.inf, -np.inf, 0.998, 1e-9], np.float32)
+    sums = np.tile(vals, 3)[: 12 * 3].reshape(12, 1, 3).copy()
+    assert np.array_equal(gpu_ctx.resolve_u8(sums, 1), orc.resolve_u8(sums, 1))
+    assert gpu_ctx.resolve_u8(sums, 1).reshape(-1)[:8].tolist() == [0, 128, 255, 255, 0, 0, 255, 1]
+    rng = np.random.default_rng(0)
+    big = (rng.uniform(-0.2, 1.3, (64, 64, 3)) * 7).astype(np.float32)
+    assert np.array_equal(gpu_ctx.resolve_u8(big, 7), orc.resolve_u8(big, 7))
+
+
+# ---- properties that do not depend on size ---------------------------------------------------------------
+def test_rank_split_sample_split_and_batch_size_change_no_bit(gpu_ctx):
+    name, w, h, spp = "final_scene", 200, 120, 6
+    gpu_ctx.load_scene(name, seed=1)
+    cam = gpu_ctx.preset_camera(w / h)
+    full, st = gpu_ctx.render(w, h, cam, spp, seed=4)
+    # 3 ranks, each into the shared buffer (disjoint pixels)
+    merged = np.zeros_like(full)
+    rays = 0
+    for r in range(3):
+        _, s = gpu_ctx.render(w, h, cam, spp, seed=4, accum=merged, rank=r, nranks=3, tile_size=16)
+        rays += s["rays"]
+    assert rays == st["rays"] and np.array_equal(merged, full)
+    # samples 0..1 then 2..5 into one buffer
+    split = np.zeros_like(full)
+    gpu_ctx.render(w, h, cam, 2, seed=4, accum=split, sample0=0)
+    gpu_ctx.render(w, h, cam, 4, seed=4, accum=split, sample0=2)
+    assert np.array_equal(split, full)
+    # tiny wavefront batches: pixel chunks of 4096 paths, one sample at a time
+    small = rtamd.Context(0, max_paths=4096)
+    small.load_scene(name, seed=1)
+    tiny, s2 = small.render(w, h, cam, spp, seed=4)
+    assert s2["batches"] > spp and s2["rays"] == st["rays"] and np.array_equal(tiny, full)
+    small.close()
+
+
+def test_device_and_host_accumulators_agree(gpu_ctx):
+    import torch
+    gpu_ctx.load_scene("cornell_box", seed=1)
+    cam = gpu_ctx.preset_camera(1.0)
+    host, _ = gpu_ctx.render(96, 96, cam, 4, seed=3)
+    dev = torch.zeros((96, 96, 3), dtype=torch.float32, device="cuda")
+    gpu_ctx.render(96, 96, cam, 4, seed=3, accum=dev)
+    assert np.array_equal(dev.cpu().numpy(), host)
+    assert np.array_equal(gpu_ctx.resolve_u8(dev, 4).cpu().numpy(), gpu_ctx.resolve_u8(host, 4))
+
+
+def test_c2_full_frame_properties(gpu_ctx):
+    """BASELINE configs[1] at its full 1920x1080 frame (reduced spp): an 8-rank split reproduces the 1-rank
+    frame bit for bit, and pixels whose samples all miss hold exactly spp sequential f32 adds of the background."""
+    import torch
+    w, aspect, spp = 1920, 16 / 9, 3
+    h = rtamd.image_height(w, aspect)
+    for name in ("earth", "two_perlin_spheres"):
+        gpu_ctx.load_scene(name, seed=1)
+        cam = gpu_ctx.preset_camera(aspect)
+        one = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        _, st = gpu_ctx.render(w, h, cam, spp, seed=1, accum=one)
+        assert st["paths"] == w * h * spp
+        eight = torch.zeros_like(one)
+        for r in range(8):
+            gpu_ctx.render(w, h, cam, spp, seed=1, accum=eight, rank=r, nranks=8)
+        assert torch.equal(one, eight)
+        if name == "earth":  # the sphere is in the middle; the corners see only background
+            bg = np.float32([0.7, 0.8, 1.0])
+            acc = np.zeros(3, np.float32)
+            for _ in range(spp):
+                acc = acc + bg
+            corner = one[:8, :8].cpu().numpy().reshape(-1, 3)
+            assert np.all(corner == acc)
+            assert float(one.mean()) / spp < 1.0
+
+
+def test_c5_like_deep_bvh_properties(gpu_ctx):
+    """The synthetic deep-BVH scene (reduced from 10M to 1M spheres for test time) at a 3840x2160 frame, 1 spp:
+    rank split reproduces the single-rank frame bit for bit and every path ends with finite radiance."""
+    import torch
+    info = gpu_ctx.load_scene("synth_spheres", seed=1, n_synth=1_000_000)
+    assert info["n_prims"] == 1_000_001 and info["stack_entries"] in (32, 64)
+    w, h = 3840, 2160
+    cam = gpu_ctx.preset_camera(16 / 9)
+    one = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    _, st = gpu_ctx.render(w, h, cam, 1, seed=1, accum=one)
+    assert st["paths"] == w * h and st["rays"] >= st["paths"]
+    assert bool(torch.isfinite(one).all()) and float(one.min()) >= 0.0 and float(one.max()) <= 1.0
+    four = torch.zeros_like(one)
+    for r in range(4):
+        gpu_ctx.render(w, h, cam, 1, seed=1, accum=four, rank=r, nranks=4)
+    assert torch.equal(one, four)
