@@ -38,9 +38,12 @@ void rt_ctx_destroy(rt_ctx* ctx);
 const char* rt_last_error(const rt_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
 int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
-/* Upper bound on paths in flight per wavefront batch (default 16Mi). */
+/* Upper bound on paths in flight per wavefront batch (default 64Mi paths, about 8 GB of wavefront buffers; env RTAMD_MAX_PATHS_MI). */
 int rt_ctx_set_max_paths(rt_ctx* ctx, uint64_t max_paths);
 int rt_ctx_synchronize(rt_ctx* ctx);
+/* Kernel pipeline of rt_render: -1 = pick per scene (default), 0 = split (ray generation, then a trace and
+ * a shade kernel per bounce), 1 = fused (one kernel per bounce).  Both produce the same bits. */
+int rt_ctx_set_pipeline(rt_ctx* ctx, int pipeline);
 
 /* ---- scene description --------------------------------------------------
  * Replaces the object graph of Arc<dyn Hittable>/Arc<dyn Material>/Arc<dyn Texture>
@@ -176,6 +179,10 @@ typedef struct rt_render_stats {
     uint64_t trace_launches, shade_launches;
     uint64_t node_visits; /* inner BVH nodes fetched   (profile flag 2, instrumented trace kernel) */
     uint64_t prim_tests;  /* primitive records tested  (profile flag 2) */
+    double bounce_ms;     /* fused pipeline: HIP-event time of the bounce kernel (profile flag 1) */
+    uint64_t bounce_kernel_launches;
+    uint32_t pipeline;    /* 1 = fused (one kernel per bounce), 0 = split (raygen, then trace + shade per bounce) */
+    uint32_t reserved;
 } rt_render_stats;
 
 int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* accum_rgb,

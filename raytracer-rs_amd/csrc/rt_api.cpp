@@ -46,7 +46,7 @@ struct HostImage {
     std::vector<uint8_t> rgb;
 };
 
-enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_COUNT = 4 };
+enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_BOUNCE = 4, KS_COUNT = 5 };
 
 }  // namespace
 
@@ -76,12 +76,15 @@ struct rt_ctx {
     rt_scene_info info{};
 
     // wavefront buffers
-    uint64_t max_paths = 16ull << 20;
+    uint64_t max_paths = 64ull << 20;
     uint64_t capacity = 0;
+    uint32_t cap_shard = 0;
+    int pipeline = -1;  // -1 choose per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce)
+    uint64_t fused_node_limit = 64;  // scenes with at most this many BVH nodes take the fused pipeline
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
     uint64_t n_owned = 0;
-    uint32_t* h_counts = nullptr;  // pinned: counts[2], overflow
+    uint32_t* h_counts = nullptr;  // pinned: NSHARD queue counts, then the overflow flag
     unsigned long long* h_rays = nullptr;
 
     // profiling
@@ -235,20 +238,27 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
     return (uint32_t)strtoul(v, nullptr, 10);
 }
 
-int alloc_wavefront(rt_ctx* c, uint64_t cap) {
-    if (c->capacity >= cap) return RT_OK;
+// Wavefront buffers for batches of up to `cap` paths.  The path queues are split into rtk::NSHARD shards
+// of cap_shard entries; the hit buffer is only needed by the split pipeline.
+int alloc_wavefront(rt_ctx* c, uint64_t cap, bool need_hits) {
     int rc;
-    for (int s = 0; s < 2; s++) {
-        for (int a = 0; a < 3; a++)
-            if ((rc = ensure(c, c->d_state[s][a], cap * sizeof(float4)))) return rc;
-        if ((rc = ensure(c, c->d_state[s][3], cap * sizeof(uint2)))) return rc;
+    if (c->capacity < cap) {
+        const uint64_t tiles = (cap + rtk::BLOCK - 1) / rtk::BLOCK;
+        const uint64_t cap_shard = ((tiles + rtk::NSHARD - 1) / rtk::NSHARD) * rtk::BLOCK;
+        const uint64_t total = cap_shard * rtk::NSHARD;
+        for (int s = 0; s < 2; s++) {
+            for (int a = 0; a < 3; a++)
+                if ((rc = ensure(c, c->d_state[s][a], total * sizeof(float4)))) return rc;
+            if ((rc = ensure(c, c->d_state[s][3], total * sizeof(uint2)))) return rc;
+        }
+        if ((rc = ensure(c, c->d_radiance, cap * sizeof(float4)))) return rc;
+        if ((rc = ensure(c, c->d_counts, 3 * rtk::NSHARD * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, c->d_rays, 32))) return rc;
+        if ((rc = ensure(c, c->d_overflow, 16))) return rc;
+        c->capacity = cap;
+        c->cap_shard = (uint32_t)cap_shard;
     }
-    if ((rc = ensure(c, c->d_hits, cap * sizeof(float4)))) return rc;
-    if ((rc = ensure(c, c->d_radiance, cap * sizeof(float4)))) return rc;
-    if ((rc = ensure(c, c->d_counts, 16))) return rc;
-    if ((rc = ensure(c, c->d_rays, 32))) return rc;
-    if ((rc = ensure(c, c->d_overflow, 16))) return rc;
-    c->capacity = cap;
+    if (need_hits && (rc = ensure(c, c->d_hits, (uint64_t)c->cap_shard * rtk::NSHARD * sizeof(float4)))) return rc;
     return RT_OK;
 }
 rtk::PathState path_state(rt_ctx* c, int s) {
@@ -307,12 +317,14 @@ int rt_ctx_create(int device, rt_ctx** out) {
         return RT_ERR_HIP;
     }
     c->stream = c->own_stream;
-    if (hipHostMalloc((void**)&c->h_counts, 64, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void**)&c->h_counts, (rtk::NSHARD + 16) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_rays, 64, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return RT_ERR_HIP;
     }
-    c->max_paths = (uint64_t)env_u32("RTAMD_MAX_PATHS_MI", 16) << 20;
+    c->max_paths = (uint64_t)env_u32("RTAMD_MAX_PATHS_MI", 64) << 20;
+    if (getenv("RTAMD_PIPELINE")) c->pipeline = (int)env_u32("RTAMD_PIPELINE", 1) ? 1 : 0;  // 0 split, 1 fused
+    c->fused_node_limit = env_u32("RTAMD_FUSED_NODE_LIMIT", 64);
     *out = c;
     return RT_OK;
 }
@@ -345,6 +357,11 @@ int rt_ctx_set_stream(rt_ctx* c, void* hip_stream) {
 int rt_ctx_set_max_paths(rt_ctx* c, uint64_t max_paths) {
     if (!c || max_paths < 1024 || max_paths > (1ull << 31)) return fail(c, RT_ERR_INVALID, "max_paths out of range");
     c->max_paths = max_paths;
+    return RT_OK;
+}
+int rt_ctx_set_pipeline(rt_ctx* c, int pipeline) {
+    if (!c || pipeline < -1 || pipeline > 1) return fail(c, RT_ERR_INVALID, "pipeline must be -1, 0 or 1");
+    c->pipeline = pipeline;
     return RT_OK;
 }
 int rt_ctx_synchronize(rt_ctx* c) {
@@ -675,7 +692,7 @@ int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, 
     if ((rc = ensure(c, c->d_overflow, 16))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
     if (dev) {
-        HIP_TRY(c, rtk::launch_intersect_batch(c->stream, c->stack_entries, c->has_groups, c->scene, n, in, tmin, tmax,
+        HIP_TRY(c, rtk::launch_intersect_batch(c->stream, rtk::TraceCfg{c->stack_entries, c->has_groups, false}, c->scene, n, in, tmin, tmax,
                                                seed, prim, inst, t, normal, front, uv, point, (uint32_t*)c->d_overflow.p));
     } else {
         // staging for host callers: rays in, requested outputs back
@@ -702,7 +719,7 @@ int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, 
         float* d_uv = (float*)(o + 28 * n);
         float* d_point = (float*)(o + 36 * n);
         if (e == hipSuccess)
-            e = rtk::launch_intersect_batch(c->stream, c->stack_entries, c->has_groups, c->scene, n, drays, tmin, tmax, seed,
+            e = rtk::launch_intersect_batch(c->stream, rtk::TraceCfg{c->stack_entries, c->has_groups, false}, c->scene, n, drays, tmin, tmax, seed,
                                             prim ? d_prim : nullptr, inst ? d_inst : nullptr, t ? d_t : nullptr,
                                             normal ? d_normal : nullptr, front ? d_front : nullptr, uv ? d_uv : nullptr,
                                             point ? d_point : nullptr, (uint32_t*)c->d_overflow.p);
@@ -722,9 +739,9 @@ int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, 
         if (e != hipSuccess) return hip_fail(c, e, "rt_intersect_batch staging");
         if (e2 != hipSuccess) return hip_fail(c, e2, "rt_intersect_batch sync");
     }
-    HIP_TRY(c, hipMemcpyAsync(c->h_counts + 2, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_counts + rtk::NSHARD, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_counts[2]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
+    if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     return RT_OK;
 }
 
@@ -805,60 +822,74 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     rt_render_stats st{};
     c->ev_used.clear();
     c->ev_next = 0;
+    // Pipeline choice: the fused bounce kernel moves the least data; the split pipeline lets the traversal
+    // run at its own, smaller register budget, which pays once a ray walks more than a handful of nodes.
+    const bool fused = c->pipeline >= 0 ? c->pipeline == 1 : c->info.n_nodes <= c->fused_node_limit;
+    st.pipeline = fused ? 1u : 0u;
     if (n_owned && n_samples_total) {
         const uint64_t cap = std::min<uint64_t>(c->max_paths, n_owned * (uint64_t)n_samples_total);
-        if ((rc = alloc_wavefront(c, std::max<uint64_t>(cap, 1024)))) return rc;
+        if ((rc = alloc_wavefront(c, std::max<uint64_t>(cap, 1024), !fused))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 24, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
-        uint32_t* counts = (uint32_t*)c->d_counts.p;
+        const rtk::Queues q{(uint32_t*)c->d_counts.p, c->cap_shard};
+        const rtk::TraceCfg tcfg{c->stack_entries, c->has_groups, c->count_visits};
+        unsigned long long* d_stats = (unsigned long long*)c->d_rays.p;
+        uint32_t* d_ovf = (uint32_t*)c->d_overflow.p;
+        float4* d_rad = (float4*)c->d_radiance.p;
         const uint64_t pix_chunk = std::min<uint64_t>(n_owned, c->capacity);
         for (uint64_t p0 = 0; p0 < n_owned; p0 += pix_chunk) {
             const uint32_t npix = (uint32_t)std::min<uint64_t>(pix_chunk, n_owned - p0);
             const uint32_t s_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_samples_total, c->capacity / npix));
-            const uint32_t* plist = (const uint32_t*)c->d_pixels.p + p0;
             for (uint32_t s = 0; s < n_samples_total; s += s_batch) {
                 const uint32_t ns = std::min(s_batch, n_samples_total - s);
-                uint32_t n_bound = npix * ns;
+                const rtk::Batch batch{(const uint32_t*)c->d_pixels.p + p0, npix, p->sample0 + s, ns};
+                const uint32_t n_batch = npix * ns;
+                // blocks per shard for the next launches, from the largest queue known so far
+                uint32_t bps = (n_batch + rtk::BLOCK * rtk::NSHARD - 1) / (rtk::BLOCK * rtk::NSHARD);
                 st.batches++;
-                st.paths += n_bound;
-                {
+                st.paths += n_batch;
+                if (fused) {
+                    HIP_TRY(c, hipMemsetAsync(q.counts, 0, 3 * rtk::NSHARD * sizeof(uint32_t), c->stream));
+                } else {
                     ScopedTimer tm(c, KS_RAYGEN);
-                    HIP_TRY(c, rtk::launch_raygen(c->stream, rcst, plist, npix, p->sample0 + s, ns, path_state(c, 0), counts,
-                                                  (float4*)c->d_radiance.p));
+                    HIP_TRY(c, rtk::launch_raygen(c->stream, rcst, batch, path_state(c, 0), q));
                 }
-                uint32_t which = 0;
                 for (uint32_t b = 0; b < p->max_depth; b++) {
-                    {
-                        ScopedTimer tm(c, KS_TRACE);
-                        HIP_TRY(c, rtk::launch_trace(c->stream, c->stack_entries, c->has_groups, c->count_visits, c->scene, path_state(c, which),
-                                                     counts, which, n_bound, (float4*)c->d_hits.p,
-                                                     (unsigned long long*)c->d_rays.p, (uint32_t*)c->d_overflow.p));
+                    const rtk::PathState in = path_state(c, b & 1), out = path_state(c, (b & 1) ^ 1);
+                    if (fused) {
+                        ScopedTimer tm(c, KS_BOUNCE);
+                        HIP_TRY(c, rtk::launch_bounce(c->stream, tcfg, c->scene, rcst, batch, in, out, q, b, bps, d_rad, d_stats, d_ovf));
+                    } else {
+                        {
+                            ScopedTimer tm(c, KS_TRACE);
+                            HIP_TRY(c, rtk::launch_trace(c->stream, tcfg, c->scene, in, q, b, bps, (float4*)c->d_hits.p, d_stats, d_ovf));
+                        }
+                        {
+                            ScopedTimer tm(c, KS_SHADE);
+                            HIP_TRY(c, rtk::launch_shade(c->stream, c->scene, rcst, in, out, (const float4*)c->d_hits.p, q, b, bps, d_rad));
+                        }
                     }
-                    {
-                        ScopedTimer tm(c, KS_SHADE);
-                        HIP_TRY(c, rtk::launch_shade(c->stream, c->scene, rcst, path_state(c, which), path_state(c, which ^ 1),
-                                                     (const float4*)c->d_hits.p, counts, which, n_bound,
-                                                     (float4*)c->d_radiance.p));
-                    }
-                    which ^= 1;
                     st.bounce_launches++;
-                    // read the live-path count back now and then: stop when no path is left, shrink the grid
+                    // read the queue lengths back now and then: stop when no path is left, shrink the grid
                     const bool check = b < 4 || (b & 3) == 3;
                     if (check && b + 1 < p->max_depth) {
-                        HIP_TRY(c, hipMemcpyAsync(c->h_counts, counts + which, 4, hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, hipMemcpyAsync(c->h_counts, q.counts + ((b + 1) % 3) * rtk::NSHARD, rtk::NSHARD * sizeof(uint32_t),
+                                                  hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(c, hipStreamSynchronize(c->stream));
-                        n_bound = c->h_counts[0];
-                        if (n_bound == 0) break;
+                        uint32_t longest = 0;
+                        for (int k = 0; k < rtk::NSHARD; k++) longest = std::max(longest, c->h_counts[k]);
+                        if (longest == 0) break;
+                        bps = (longest + rtk::BLOCK - 1) / rtk::BLOCK;
                     }
                 }
                 {
                     ScopedTimer tm(c, KS_ACCUM);
-                    HIP_TRY(c, rtk::launch_accumulate(c->stream, (const float4*)c->d_radiance.p, plist, npix, ns, d_accum));
+                    HIP_TRY(c, rtk::launch_accumulate(c->stream, (const float4*)c->d_radiance.p, batch, d_accum));
                 }
             }
         }
         HIP_TRY(c, hipMemcpyAsync(c->h_rays, c->d_rays.p, 24, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_counts + 2, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_counts + rtk::NSHARD, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
     }
     if (!accum_dev) HIP_TRY(c, hipMemcpyAsync(accum_rgb, d_accum, accum_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -866,20 +897,22 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         st.rays = c->h_rays[0];
         st.node_visits = c->h_rays[1];
         st.prim_tests = c->h_rays[2];
-        if (c->h_counts[2]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
+        if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     }
     if (c->profile) {
-        double ms[KS_COUNT] = {0, 0, 0, 0};
+        double ms[KS_COUNT] = {0, 0, 0, 0, 0};
         for (auto& u : c->ev_used) {
             float t = 0;
             if (hipEventElapsedTime(&t, c->ev_pool[u.second.first], c->ev_pool[u.second.second]) == hipSuccess) ms[u.first] += t;
             if (u.first == KS_TRACE) st.trace_launches++;
             if (u.first == KS_SHADE) st.shade_launches++;
+            if (u.first == KS_BOUNCE) st.bounce_kernel_launches++;
         }
         st.raygen_ms = ms[KS_RAYGEN];
         st.trace_ms = ms[KS_TRACE];
         st.shade_ms = ms[KS_SHADE];
         st.accumulate_ms = ms[KS_ACCUM];
+        st.bounce_ms = ms[KS_BOUNCE];
     }
     st.render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = st;

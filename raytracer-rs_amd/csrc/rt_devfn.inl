@@ -1,0 +1,567 @@
+// Device functions of the path tracer: vector helpers, counter-based RNG, primitive tests, BVH traversal,
+// hit records, textures and materials.  Included by rt_kernels.hip only.
+//
+// Arithmetic rules.  Everything that decides WHICH primitive is hit and at what t is written in the
+// operation order of the Rust reference and compiled with -ffp-contract=off (rustc never fuses a*b+c);
+// HIP's f32 divide and sqrt are correctly rounded by default.  Box slab tests only cull, so they use a
+// fast reciprocal and are padded to stay conservative.  No MFMA: nothing here is a dense contraction.
+#include "rt_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+using namespace rtd;
+
+#define DEV __device__ __forceinline__
+
+namespace {
+
+constexpr float INF_F = __builtin_huge_valf();
+constexpr float F32_EPSILON = 1.1920929e-7f;
+constexpr float PI_F = 3.14159265358979323846f;
+
+struct f3 {
+    float x, y, z;
+};
+DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+DEV f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
+DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+DEV f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }  // glam: (x*x + y*y) + z*z
+DEV float len3(f3 a) { return __builtin_sqrtf(dot3(a, a)); }
+DEV f3 normalize3(f3 a) { return a / len3(a); }
+DEV float comp(f3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+
+// 3x4 row-major affine maps in glam's accumulation order
+DEV f3 xf_point(const float* m, f3 v) {
+    return {((m[0] * v.x + m[1] * v.y) + m[2] * v.z) + m[3], ((m[4] * v.x + m[5] * v.y) + m[6] * v.z) + m[7],
+            ((m[8] * v.x + m[9] * v.y) + m[10] * v.z) + m[11]};
+}
+DEV f3 xf_vector(const float* m, f3 v) {
+    return {(m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
+            (m[8] * v.x + m[9] * v.y) + m[10] * v.z};
+}
+
+// ---- counter-based RNG ------------------------------------------------------
+//   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
+//   stream (seed,pixel,sample): h=mix32(seed^0x51ED270B); k0=mix32(pixel^h);
+//       k1=mix32(k0^mix32(sample+0x68E31DA4)); draw n = mix32(mix32(k0+n)^k1)
+DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+struct Rng {
+    uint32_t k0, k1, n;
+    DEV uint32_t next() {
+        uint32_t r = mix32(mix32(k0 + n) ^ k1);
+        n++;
+        return r;
+    }
+    DEV float f32() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }  // rand gen::<f32>()
+    DEV float range(float lo, float hi) {                                       // rand gen_range(lo..hi)
+        float scale = hi - lo;
+        for (;;) {
+            float v12 = __uint_as_float(0x3f800000U | (next() >> 9));
+            float v01 = v12 - 1.0f;
+            float r = v01 * scale + lo;
+            if (r < hi) return r;
+        }
+    }
+};
+DEV void stream_key(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t& k0, uint32_t& k1) {
+    uint32_t h = mix32(seed ^ 0x51ED270BU);
+    k0 = mix32(pixel ^ h);
+    k1 = mix32(k0 ^ mix32(sample + 0x68E31DA4U));
+}
+// f64 uniform of medium `m` at bounce `b`: rand gen_range(0.0..1.0) from a (hi,lo) word pair
+DEV double medium_xi(uint32_t k0, uint32_t k1, uint32_t bounce, uint32_t medium) {
+    uint32_t salt = mix32(medium + 0x3C6EF372U);
+    uint32_t hi = mix32(mix32(k0 + 0x80000000U + 2u * bounce) ^ k1 ^ salt);
+    uint32_t lo = mix32(mix32(k0 + 0x80000001U + 2u * bounce) ^ k1 ^ salt);
+    unsigned long long u = ((unsigned long long)hi << 32) | lo;
+    return __longlong_as_double((long long)((u >> 12) | 0x3FF0000000000000ULL)) - 1.0;
+}
+DEV f3 rand_range3(Rng& r, float lo, float hi) {
+    float x = r.range(lo, hi), y = r.range(lo, hi), z = r.range(lo, hi);
+    return {x, y, z};
+}
+DEV f3 rand_in_unit_sphere(Rng& r) {  // vec3_helpers.rs:25-31
+    f3 p = rand_range3(r, -1.0f, 1.0f);
+    while (dot3(p, p) >= 1.0f) p = rand_range3(r, -1.0f, 1.0f);
+    return p;
+}
+
+// ---- primitives ---------------------------------------------------------------
+struct Hit {
+    float t;
+    uint32_t prim;  // index into prims[], HIT_NONE, or HIT_MEDIUM_BIT | group
+    int grp;        // instance group of the hit primitive, or -1
+    uint32_t key;   // tie key: caller id of the primitive, MEDIUM_KEY_BASE + k for media
+};
+
+DEV f3 moving_center(const Scene& S, f3 c0, uint32_t aux, float time) {  // shapes.rs:189-191
+    const float4* mp = reinterpret_cast<const float4*>(S.moving + aux);
+    float4 m0 = mp[0], m1 = mp[1];
+    f3 c1{m0.x, m0.y, m0.z};
+    float t0 = m0.w, t1 = m1.x;
+    return c0 + (((time - t0) / (t1 - t0)) * (c1 - c0));
+}
+
+// Candidate t of one primitive in [tmin, tmax] (inclusive, as the reference's "< t_min || > t_max" rejects).
+DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out,
+                        uint32_t& id_out) {
+    const float4* pp = reinterpret_cast<const float4*>(S.prims + pi);
+    float4 A = pp[0];
+    float4 B = pp[1];
+    uint32_t info = __float_as_uint(B.y);
+    id_out = __float_as_uint(B.z);
+    uint32_t kind = info & 7u;
+    float t;
+    if (kind <= PK_MOVING_SPHERE) {  // shapes.rs:117-139, 195-217
+        f3 c{A.x, A.y, A.z};
+        if (kind == PK_MOVING_SPHERE) c = moving_center(S, c, __float_as_uint(B.w), time);
+        float r = A.w;
+        f3 oc = o - c;
+        float half_b = dot3(oc, d);
+        float cc = dot3(oc, oc) - r * r;
+        float disc = half_b * half_b - a * cc;
+        if (disc < 0.0f) return false;
+        float sq = __builtin_sqrtf(disc);
+        t = (-half_b - sq) / a;
+        if (t < tmin || t > tmax) {
+            t = (-half_b + sq) / a;
+            if (t < tmin || t > tmax) return false;
+        }
+    } else {  // shapes.rs:279-292, 343-356, 407-420
+        int ax = kind == PK_RECT_XY ? 2 : (kind == PK_RECT_XZ ? 1 : 0);
+        int a0 = ax == 0 ? 1 : 0;
+        int a1 = ax == 2 ? 1 : 2;
+        t = (A.x - comp(o, ax)) / comp(d, ax);
+        if (t < tmin || t > tmax) return false;
+        float x = comp(o, a0) + t * comp(d, a0);
+        float y = comp(o, a1) + t * comp(d, a1);
+        if (x < A.y || x > A.w || y < A.z || y > B.x) return false;
+    }
+    t_out = t;
+    return true;
+}
+
+// Closest-hit update with the exact-tie rule "higher id wins" (scene.rs:32-38: the later shape wins).
+DEV void test_prim(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time, float tmin, int grp, Hit& best) {
+    float t;
+    uint32_t id;
+    if (!prim_candidate(S, pi, o, d, a, time, tmin, best.t, t, id)) return;
+    if (t == best.t && best.prim != HIT_NONE && id < best.key) return;
+    best.t = t;
+    best.prim = pi;
+    best.grp = grp;
+    best.key = id;
+}
+
+// Scene::intersect over a short primitive list (scene.rs:27-41); only t is needed by the medium.
+DEV bool list_closest(const Scene& S, uint32_t ref, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out) {
+    uint32_t first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 15u) + 1u;
+    float closest = tmax;
+    bool any = false;
+    for (uint32_t i = 0; i < cnt; i++) {
+        float t;
+        uint32_t id;
+        if (prim_candidate(S, first + i, o, d, a, time, tmin, closest, t, id)) {
+            closest = t;
+            any = true;
+        }
+    }
+    t_out = closest;
+    return any;
+}
+
+// ConstantMedium::intersect (shapes.rs:648-701).  wo/wd: the world ray.  A medium that reports a hit
+// replaces the closest hit so far unchecked, as Scene::intersect does (scene.rs:33-37): its final_t may
+// lie beyond best.t because shapes.rs:676-683 divides by the ray length twice.
+DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1,
+                     uint32_t bounce, Hit& best) {
+    const Group& G = S.groups[g];
+    f3 o = wo, d = wd;
+    if (G.has_xform) {  // TransformedObject as the boundary (shapes.rs:66-70); t is shared between spaces
+        o = xf_point(G.minv, wo);
+        d = xf_vector(G.minv, wd);
+    }
+    float a = dot3(d, d);
+    float r1, r2;
+    if (!list_closest(S, G.root_ref, o, d, a, time, -INF_F, INF_F, r1)) return;
+    if (!list_closest(S, G.root_ref, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
+    if (r1 < tmin) r1 = tmin;
+    if (r2 > best.t) r2 = best.t;
+    if (r1 >= r2) return;
+    if (r1 < 0.0f) r1 = 0.0f;
+    double len = (double)len3(wd);
+    double inside = (double)(r2 - r1) / len;
+    double xi = medium_xi(k0, k1, bounce, G.order);
+    double hit_distance = G.neg_inv_density * log(xi);
+    if (hit_distance > inside) return;
+    best.t = r1 + (float)(hit_distance / len);
+    best.prim = HIT_MEDIUM_BIT | g;
+    best.grp = -1;
+    best.key = MEDIUM_KEY_BASE + G.order;
+}
+
+DEV float pad_up(float x) { return x + __builtin_fabsf(x) * 6e-7f; }
+DEV float pad_down(float x) { return x - __builtin_fabsf(x) * 6e-7f; }
+DEV f3 fast_rcp3(f3 d) { return {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)}; }
+
+// Conservative slab test: entry distance in tn; true when [tn, tf] overlaps [tmin, tbest] after padding.
+// fminf/fmaxf ignore NaN (0 * inf when a direction component is zero and the origin lies on a slab plane).
+DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tmin, float tbest, float& tn) {
+    float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
+    float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
+    float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
+    float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    tn = n;
+    float fp = pad_up(f);
+    return (pad_down(n) <= fp) && (fp >= tmin) && (pad_down(n) <= tbest);
+}
+
+// Short-stack traversal of the two-level BVH.  stk points at this lane's column of the LDS stack;
+// consecutive entries are STRIDE words apart so that the 64 lanes of a wave hit 64 different banks.
+struct TraceCount {
+    uint32_t nodes, prims;  // inner nodes fetched, primitive records tested (instrumented builds only)
+};
+template <int STRIDE, int STACK, bool GROUPS, bool COUNT = false>
+DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
+                   uint32_t bounce, Hit& best, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
+    best.t = tmax;
+    best.prim = HIT_NONE;
+    best.grp = -1;
+    best.key = 0;
+    uint32_t cur = S.root_ref;
+    f3 o = wo, d = wd;
+    float a = dot3(d, d);
+    f3 inv = fast_rcp3(d);
+    int grp = -1;
+    int sp = 0;
+    // "while-while": the inner loop walks inner nodes only, so that lanes of a wave that are still
+    // descending do not drag the (long) primitive tests of the others along on every iteration.
+    // cur == REF_EMPTY means this lane has nothing left.
+    for (;;) {
+        while ((cur >> 30) == REF_INNER) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (COUNT) cnt->nodes++;
+            float tn0, tn1;
+            bool h0 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, tn0);
+            bool h1 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv, tmin, best.t, tn1);
+            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            h0 = h0 && (c0 != REF_EMPTY);
+            h1 = h1 && (c1 != REF_EMPTY);
+            if (h0 || h1) {
+                bool first1 = h1 && (!h0 || tn1 < tn0);
+                cur = first1 ? c1 : c0;
+                if (h0 && h1) {
+                    if (sp < STACK) {
+                        stk[sp * STRIDE] = first1 ? c0 : c1;
+                        sp++;
+                    } else {
+                        *overflow_flag = 1u;
+                    }
+                }
+            } else if (sp > 0) {
+                sp--;
+                cur = stk[sp * STRIDE];
+            } else {
+                cur = REF_EMPTY;
+            }
+        }
+        if (cur == REF_EMPTY) break;
+        const uint32_t type = cur >> 30;
+        if (type == REF_PRIMS) {
+            uint32_t first = cur & 0x03FFFFFFu, n_leaf = ((cur >> 26) & 15u) + 1u;
+            for (uint32_t i = 0; i < n_leaf; i++) test_prim(S, first + i, o, d, a, time, tmin, grp, best);
+            if (COUNT) cnt->prims += n_leaf;
+            cur = REF_EMPTY;
+        } else if (GROUPS && type == REF_INSTANCE) {
+            uint32_t g = cur & 0x3FFFFFFFu;
+            const Group& G = S.groups[g];
+            uint32_t root = G.root_ref;
+            cur = REF_EMPTY;
+            if (root != REF_EMPTY) {
+                if (sp < STACK) {
+                    if (G.has_xform) {  // shapes.rs:66-70
+                        o = xf_point(G.minv, wo);
+                        d = xf_vector(G.minv, wd);
+                        a = dot3(d, d);
+                        inv = fast_rcp3(d);
+                    }
+                    stk[sp * STRIDE] = REF_SENTINEL;
+                    sp++;
+                    grp = (int)g;
+                    cur = root;
+                } else {
+                    *overflow_flag = 1u;
+                }
+            }
+        } else {  // REF_SENTINEL: the instance's subtree is finished, back to the world ray
+            o = wo;
+            d = wd;
+            a = dot3(d, d);
+            inv = fast_rcp3(d);
+            grp = -1;
+            cur = REF_EMPTY;
+        }
+        if (cur == REF_EMPTY) {  // next entry from the stack
+            if (sp == 0) break;
+            sp--;
+            cur = stk[sp * STRIDE];
+        }
+    }
+    // media come after all surfaces, in creation order (the order of a Scene whose media were added last)
+    if (GROUPS)
+        for (uint32_t m = 0; m < S.n_media; m++) {
+            test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
+            if (COUNT) cnt->prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);  // two boundary queries
+        }
+}
+
+// ---- hit record (hit_record.rs, shapes.rs) --------------------------------------
+struct Record {
+    f3 point, normal;
+    float u, v;
+    bool front;
+    uint32_t mat;
+};
+DEV void sphere_uv(f3 p, float& u, float& v) {  // shapes.rs:19-24
+    float theta = acosf(-p.y);
+    float phi = atan2f(-p.z, p.x) + PI_F;
+    u = phi / (2.0f * PI_F);
+    v = theta / PI_F;
+}
+template <bool WANT_UV>
+DEV void make_record(const Scene& S, f3 wo, f3 wd, float time, const Hit& h, Record& rec) {
+    if (h.prim & HIT_MEDIUM_BIT) {  // shapes.rs:690-697
+        const Group& G = S.groups[h.prim & 0x3FFFFFFFu];
+        rec.point = wo + (h.t * wd);
+        rec.normal = {1.0f, 0.0f, 0.0f};
+        rec.front = true;
+        rec.u = 0.0f;
+        rec.v = 0.0f;
+        rec.mat = G.mat;
+        return;
+    }
+    f3 o = wo, d = wd;
+    const Group* G = nullptr;
+    if (h.grp >= 0) {
+        G = S.groups + h.grp;
+        if (G->has_xform) {
+            o = xf_point(G->minv, wo);
+            d = xf_vector(G->minv, wd);
+        } else {
+            G = nullptr;
+        }
+    }
+    const float4* pp = reinterpret_cast<const float4*>(S.prims + h.prim);
+    float4 A = pp[0], B = pp[1];
+    uint32_t info = __float_as_uint(B.y);
+    uint32_t kind = info & 7u;
+    rec.mat = info >> 8;
+    f3 point = o + (h.t * d);
+    f3 outward;
+    rec.u = 0.0f;
+    rec.v = 0.0f;
+    if (kind <= PK_MOVING_SPHERE) {  // shapes.rs:141-153
+        f3 c{A.x, A.y, A.z};
+        if (kind == PK_MOVING_SPHERE) c = moving_center(S, c, __float_as_uint(B.w), time);
+        outward = (point - c) / A.w;
+        if (WANT_UV) sphere_uv(outward, rec.u, rec.v);
+    } else {  // shapes.rs:294-303
+        int ax = kind == PK_RECT_XY ? 2 : (kind == PK_RECT_XZ ? 1 : 0);
+        int a0 = ax == 0 ? 1 : 0;
+        int a1 = ax == 2 ? 1 : 2;
+        outward = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f};
+        if (WANT_UV) {
+            rec.u = (comp(point, a0) - A.y) / (A.w - A.y);
+            rec.v = (comp(point, a1) - A.z) / (B.x - A.z);
+        }
+    }
+    bool front = dot3(d, outward) < 0.0f;  // hit_record.rs:32-42
+    f3 normal = front ? outward : -outward;
+    if (G) {  // shapes.rs:74-88: normal through M (not its inverse transpose), then face-set again
+        f3 nw = normalize3(xf_vector(G->m, normal));
+        point = xf_point(G->m, point);
+        front = dot3(wd, nw) < 0.0f;
+        normal = front ? nw : -nw;
+    }
+    rec.point = point;
+    rec.normal = normal;
+    rec.front = front;
+}
+
+// ---- textures (texture.rs, perlin.rs) -------------------------------------------
+DEV float perlin_noise(const PerlinTable& P, f3 p) {  // perlin.rs:46-88
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float uu = u * u * (3.0f - 2.0f * u);
+    float vv = v * v * (3.0f - 2.0f * v);
+    float ww = w * w * (3.0f - 2.0f * w);
+    float acc = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                int idx = P.perm[0][(uint32_t)(i + di) & 255u] ^ P.perm[1][(uint32_t)(j + dj) & 255u] ^
+                          P.perm[2][(uint32_t)(k + dk) & 255u];
+                const float4 c4 = *reinterpret_cast<const float4*>(P.vec[idx & 255]);
+                f3 c{c4.x, c4.y, c4.z};
+                f3 weight{u - (float)di, v - (float)dj, w - (float)dk};
+                float wu = di ? uu : (1.0f - uu);
+                float wv = dj ? vv : (1.0f - vv);
+                float wwv = dk ? ww : (1.0f - ww);
+                acc += wu * wv * wwv * dot3(weight, c);
+            }
+    return acc;
+}
+DEV float perlin_turb(const PerlinTable& P, f3 p, int depth) {  // perlin.rs:90-102
+    float acc = 0.0f;
+    f3 temp = p;
+    float weight = 1.0f;
+    for (int i = 0; i < depth; i++) {
+        acc += weight * perlin_noise(P, temp);
+        weight *= 0.5f;
+        temp = 2.0f * temp;
+    }
+    return __builtin_fabsf(acc);
+}
+DEV float rust_clamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+DEV uint32_t rust_as_u32(float f) {  // saturating, NaN -> 0
+    if (!(f == f)) return 0u;
+    if (f <= 0.0f) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+DEV bool tex_needs_uv(const Scene& S, uint32_t ti) {
+    Texture t = S.texs[ti];
+    return t.kind == TK_IMAGE || t.kind == TK_CHECKER;  // a checker may nest an image
+}
+DEV f3 tex_value(const Scene& S, uint32_t ti, float u, float v, f3 p) {
+    const float4* tp = reinterpret_cast<const float4*>(S.texs + ti);
+    float4 T0 = tp[0], T1 = tp[1];
+    uint32_t kind = __float_as_uint(T0.x);
+    for (int it = 0; it < 8 && kind == TK_CHECKER; it++) {  // texture.rs:52-62
+        float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
+        ti = sines < 0.0f ? __float_as_uint(T1.x) : __float_as_uint(T1.y);
+        tp = reinterpret_cast<const float4*>(S.texs + ti);
+        T0 = tp[0];
+        T1 = tp[1];
+        kind = __float_as_uint(T0.x);
+    }
+    if (kind == TK_NOISE) {  // texture.rs:78-82
+        const PerlinTable& P = S.perlin[__float_as_uint(T1.w)];
+        float s = 1.0f + sinf(T1.z * p.z + 10.0f * perlin_turb(P, p, 7));
+        return {0.5f * s, 0.5f * s, 0.5f * s};
+    }
+    if (kind == TK_IMAGE) {  // texture.rs:96-117
+        const Image im = S.images[__float_as_uint(T1.w)];
+        float cu = rust_clamp(u, 0.0f, 1.0f);
+        float cv = 1.0f - rust_clamp(v, 0.0f, 1.0f);
+        uint32_t i = rust_as_u32(cu * (float)im.w);
+        uint32_t j = rust_as_u32(cv * (float)im.h);
+        if (i >= im.w) i = im.w - 1;
+        if (j >= im.h) j = im.h - 1;
+        const uint8_t* px = im.rgb + 3ull * ((unsigned long long)j * im.w + i);
+        return {(float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f};
+    }
+    return {T0.y, T0.z, T0.w};  // texture.rs:18-22
+}
+
+// ---- materials (materials.rs, vec3_helpers.rs) ------------------------------------
+DEV f3 reflect3(f3 v, f3 n) {  // vec3_helpers.rs:62-66
+    float scalar = 2.0f * dot3(v, n);
+    return v - scalar * n;
+}
+DEV f3 refract3(f3 uv, f3 n, float ratio) {  // vec3_helpers.rs:68-75
+    float dot_p = dot3(n, -uv);
+    float cos_theta = fminf(dot_p, 1.0f);
+    f3 perp = ratio * (uv + cos_theta * n);
+    f3 par = (-__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)))) * n;
+    return perp + par;
+}
+DEV float reflectance(float cosine, float ref_index) {  // materials.rs:109-114
+    float r0 = (1.0f - ref_index) / (1.0f + ref_index);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * powf(1.0f - cosine, 5.0f);
+}
+// returns true when the path continues; att and the scattered direction are set then
+DEV bool scatter(const Scene& S, const Material& M, f3 wd, const Record& rec, Rng& rng, f3& att, f3& dir) {
+    switch (M.kind) {
+        case MK_LAMBERTIAN: {  // materials.rs:45-61
+            f3 sc = rec.normal + normalize3(rand_in_unit_sphere(rng));
+            if (__builtin_fabsf(sc.x) < F32_EPSILON && __builtin_fabsf(sc.y) < F32_EPSILON && __builtin_fabsf(sc.z) < F32_EPSILON)
+                sc = rec.normal;
+            dir = sc;
+            att = tex_value(S, M.tex, rec.u, rec.v, rec.point);
+            return true;
+        }
+        case MK_METAL: {  // materials.rs:84-95 (draws even when fuzz == 0)
+            f3 reflected = reflect3(normalize3(wd), rec.normal);
+            dir = reflected + M.fuzz * rand_in_unit_sphere(rng);
+            att = ld3(M.albedo);
+            return dot3(dir, rec.normal) > 0.0f;
+        }
+        case MK_DIELECTRIC: {  // materials.rs:117-148
+            att = {1.0f, 1.0f, 1.0f};
+            float ratio = rec.front ? 1.0f / M.ior : M.ior;
+            f3 unit = normalize3(wd);
+            float cos_theta = fminf(dot3(rec.normal, -unit), 1.0f);
+            float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+            bool cannot_refract = ratio * sin_theta > 1.0f;
+            if (cannot_refract || reflectance(cos_theta, ratio) > rng.f32())
+                dir = reflect3(unit, rec.normal);
+            else
+                dir = refract3(unit, rec.normal, ratio);
+            return true;
+        }
+        case MK_ISOTROPIC: {  // materials.rs:204-215
+            dir = normalize3(rand_in_unit_sphere(rng));
+            att = tex_value(S, M.tex, rec.u, rec.v, rec.point);
+            return true;
+        }
+        default:  // MK_LIGHT, materials.rs:176-179
+            return false;
+    }
+}
+
+DEV Material load_material(const Scene& S, uint32_t mi) {
+    const float4* mp = reinterpret_cast<const float4*>(S.mats + mi);
+    float4 m0 = mp[0], m1 = mp[1];
+    Material M;
+    M.kind = __float_as_uint(m0.x);
+    M.tex = __float_as_uint(m0.y);
+    M.albedo[0] = m0.z;
+    M.albedo[1] = m0.w;
+    M.albedo[2] = m1.x;
+    M.fuzz = m1.y;
+    M.ior = m1.z;
+    M.pad = 0;
+    return M;
+}
+DEV bool material_needs_uv(const Scene& S, const Material& M) {
+    if (M.kind == MK_METAL || M.kind == MK_DIELECTRIC) return false;
+    return tex_needs_uv(S, M.tex);
+}
+
+DEV uint32_t lane_prefix(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+
+}  // namespace

@@ -7,12 +7,26 @@
 
 namespace rtk {
 
-// Wavefront path state, structure of arrays, 56 B per path.
+constexpr int BLOCK = 256;
+// Live paths are kept in NSHARD independent queues.  A block appends its survivors to the queue it read
+// from with ONE atomic per 256 paths; with a single queue that word saturates (about 90 returning
+// atomics per microsecond on one address) and bounds the whole shade step, with 64 words it does not.
+constexpr int NSHARD = 64;
+constexpr int MAX_BLOCKS_PER_SHARD = 32;  // 2048 blocks = 8 per CU; larger queues are grid-strided
+
+// Wavefront path state, structure of arrays, 56 B per path; element (shard s, i) lives at s*cap_shard + i.
 struct PathState {
     float4* o_time;    // origin.xyz, time
     float4* d_slot;    // direction.xyz, bits(slot)
     float4* thr_meta;  // throughput.xyz, bits(bounce << 24 | rng counter)
     uint2* key;        // RNG stream key (k0, k1)
+};
+
+// counts: 3 x NSHARD words.  Bounce b reads counts[b % 3], appends to counts[(b + 1) % 3] and clears
+// counts[(b + 2) % 3] for the bounce after it.
+struct Queues {
+    uint32_t* counts;
+    uint32_t cap_shard;  // entries per shard, multiple of BLOCK
 };
 
 struct RenderConst {
@@ -23,25 +37,39 @@ struct RenderConst {
     uint32_t max_depth;
 };
 
-constexpr int BLOCK = 256;
-constexpr int MAX_GRID = 256 * 8;  // 8 blocks per CU; larger batches grid-stride
+// one wavefront batch: npix pixels (pixel_list) x n_samples samples starting at sample0
+struct Batch {
+    const uint32_t* pixel_list;
+    uint32_t npix, sample0, n_samples;
+};
 
-// stack_entries: 16, 32 or 64 (per-lane traversal stack in LDS); has_groups: scene holds instances/media
-hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const uint32_t* pixel_list, uint32_t npix_batch,
-                         uint32_t sample0, uint32_t n_samples, PathState out, uint32_t* counts, float4* radiance);
-// rays_total: three 64-bit words: [0] += rays traced; with count_visits also [1] += inner nodes fetched,
-// [2] += primitive records tested (instrumented, slower kernel; used to price the algorithmic bytes per ray)
-hipError_t launch_trace(hipStream_t s, int stack_entries, bool has_groups, bool count_visits, const rtd::Scene& scene,
-                        PathState in, uint32_t* counts, uint32_t which, uint32_t n_bound, float4* hits,
-                        unsigned long long* rays_total, uint32_t* overflow_flag);
+struct TraceCfg {
+    int stack_entries;  // 16, 32 or 64: per-lane traversal stack in LDS
+    bool has_groups;    // scene holds instances / media
+    bool count_visits;  // instrumented traversal (node / primitive counters)
+};
+
+// stats: three 64-bit words: [0] += rays traced; with count_visits also [1] += inner nodes fetched,
+// [2] += primitive records tested.
+
+// ---- split pipeline: raygen, then per bounce trace + shade --------------------------------------------
+hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q);
+hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, PathState in, Queues q,
+                        uint32_t bounce, uint32_t blocks_per_shard, float4* hits, unsigned long long* stats,
+                        uint32_t* overflow_flag);
 hipError_t launch_shade(hipStream_t s, const rtd::Scene& scene, const RenderConst& rc, PathState in, PathState out,
-                        const float4* hits, uint32_t* counts, uint32_t which, uint32_t n_bound, float4* radiance);
-hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const uint32_t* pixel_list, uint32_t npix_batch,
-                             uint32_t n_samples, float* accum_rgb);
+                        const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance);
+// ---- fused pipeline: one kernel per bounce (bounce 0 generates its camera rays itself) ---------------------
+hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc,
+                         const Batch& batch, PathState in, PathState out, Queues q, uint32_t bounce,
+                         uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
+                         uint32_t* overflow_flag);
+
+hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, float* accum_rgb);
 hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, uint8_t* out);
-hipError_t launch_intersect_batch(hipStream_t s, int stack_entries, bool has_groups, const rtd::Scene& scene,
-                                  uint64_t n, const float* const rays[7], float tmin, float tmax, uint32_t seed,
-                                  int32_t* prim, int32_t* inst, float* t, float* normal, uint8_t* front, float* uv,
-                                  float* point, uint32_t* overflow_flag);
+hipError_t launch_intersect_batch(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, uint64_t n,
+                                  const float* const rays[7], float tmin, float tmax, uint32_t seed, int32_t* prim,
+                                  int32_t* inst, float* t, float* normal, uint8_t* front, float* uv, float* point,
+                                  uint32_t* overflow_flag);
 
 }  // namespace rtk

@@ -1,759 +1,291 @@
-// HIP kernels of the wavefront path tracer (gfx950 / CDNA4, wave64).
+// HIP kernels of the wavefront path tracer (gfx950 / CDNA4, wave64, 256-thread blocks).
 //
-// Kernels:
-//   k_raygen          camera samples -> path state            (main.rs:471-474, camera.rs:54-65)
-//   k_trace           closest hit of every live path          (bvh_node.rs:145-164 + shapes.rs intersect fns)
-//   k_shade           hit record, emitted, scatter, compaction (main.rs:44-63, materials.rs, texture.rs)
-//   k_accumulate      per-pixel sum in sample order            (main.rs:478-481)
-//   k_resolve         quantise                                 (main.rs:307-313)
-//   k_intersect_batch hit() path on caller-supplied rays
+//   k_bounce<PRIMARY>  fused bounce: (camera ray | queued ray) -> closest hit -> shade -> compacted queue
+//   k_raygen           camera samples -> path state            (main.rs:471-474, camera.rs:54-65)
+//   k_trace            closest hit of every live path          (bvh_node.rs:145-164 + shapes.rs intersect fns)
+//   k_shade            hit record, emitted, scatter, compaction (main.rs:44-63, materials.rs, texture.rs)
+//   k_accumulate       per-pixel sum in sample order            (main.rs:478-481)
+//   k_resolve          quantise                                 (main.rs:307-313)
+//   k_intersect_batch  hit() path on caller-supplied rays
 //
-// Arithmetic rules.  Everything that decides WHICH primitive is hit and at what t is written
-// in the operation order of the Rust reference and compiled with -ffp-contract=off
-// (rustc never fuses a*b+c); HIP's f32 divide and sqrt are correctly rounded by default.
-// Box slab tests only cull, so they use a fast reciprocal and are padded to stay conservative.
-// No MFMA anywhere: nothing on this path is a dense contraction.
-#include "rt_kernels.h"
-
-#include <hip/hip_runtime.h>
-
-using namespace rtd;
-
-#define DEV __device__ __forceinline__
+// Two pipelines share the device functions of rt_devfn.inl:
+//   fused: one k_bounce launch per bounce.  A ray's state is read once and written once per bounce, the
+//          hit record never touches memory and bounce 0 generates its camera rays in registers.
+//   split: k_raygen, then k_trace + k_shade per bounce.  The trace kernel then runs at its own (much
+//          smaller) register budget, which pays when traversal dominates.
+// Live paths sit in NSHARD queues (see rt_kernels.h); queue s is served by blocks s, s+NSHARD, ...
+#include "rt_devfn.inl"
 
 namespace {
 
-constexpr float INF_F = __builtin_huge_valf();
-constexpr float F32_EPSILON = 1.1920929e-7f;
-constexpr float PI_F = 3.14159265358979323846f;
-
-struct f3 {
-    float x, y, z;
-};
-DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
-DEV f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
-DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-DEV f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
-DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
-DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
-DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }  // glam: (x*x + y*y) + z*z
-DEV float len3(f3 a) { return __builtin_sqrtf(dot3(a, a)); }
-DEV f3 normalize3(f3 a) { return a / len3(a); }
-DEV float comp(f3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
-
-// 3x4 row-major affine maps in glam's accumulation order
-DEV f3 xf_point(const float* m, f3 v) {
-    return {((m[0] * v.x + m[1] * v.y) + m[2] * v.z) + m[3], ((m[4] * v.x + m[5] * v.y) + m[6] * v.z) + m[7],
-            ((m[8] * v.x + m[9] * v.y) + m[10] * v.z) + m[11]};
-}
-DEV f3 xf_vector(const float* m, f3 v) {
-    return {(m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
-            (m[8] * v.x + m[9] * v.y) + m[10] * v.z};
-}
-
-// ---- counter-based RNG ------------------------------------------------------
-//   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
-//   stream (seed,pixel,sample): h=mix32(seed^0x51ED270B); k0=mix32(pixel^h);
-//       k1=mix32(k0^mix32(sample+0x68E31DA4)); draw n = mix32(mix32(k0+n)^k1)
-DEV uint32_t mix32(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x7feb352dU;
-    x ^= x >> 15;
-    x *= 0x846ca68bU;
-    x ^= x >> 16;
-    return x;
-}
-struct Rng {
-    uint32_t k0, k1, n;
-    DEV uint32_t next() {
-        uint32_t r = mix32(mix32(k0 + n) ^ k1);
-        n++;
-        return r;
-    }
-    DEV float f32() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }  // rand gen::<f32>()
-    DEV float range(float lo, float hi) {                                       // rand gen_range(lo..hi)
-        float scale = hi - lo;
-        for (;;) {
-            float v12 = __uint_as_float(0x3f800000U | (next() >> 9));
-            float v01 = v12 - 1.0f;
-            float r = v01 * scale + lo;
-            if (r < hi) return r;
-        }
-    }
-};
-DEV void stream_key(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t& k0, uint32_t& k1) {
-    uint32_t h = mix32(seed ^ 0x51ED270BU);
-    k0 = mix32(pixel ^ h);
-    k1 = mix32(k0 ^ mix32(sample + 0x68E31DA4U));
-}
-// f64 uniform of medium `m` at bounce `b`: rand gen_range(0.0..1.0) from a (hi,lo) word pair
-DEV double medium_xi(uint32_t k0, uint32_t k1, uint32_t bounce, uint32_t medium) {
-    uint32_t salt = mix32(medium + 0x3C6EF372U);
-    uint32_t hi = mix32(mix32(k0 + 0x80000000U + 2u * bounce) ^ k1 ^ salt);
-    uint32_t lo = mix32(mix32(k0 + 0x80000001U + 2u * bounce) ^ k1 ^ salt);
-    unsigned long long u = ((unsigned long long)hi << 32) | lo;
-    return __longlong_as_double((long long)((u >> 12) | 0x3FF0000000000000ULL)) - 1.0;
-}
-DEV f3 rand_range3(Rng& r, float lo, float hi) {
-    float x = r.range(lo, hi), y = r.range(lo, hi), z = r.range(lo, hi);
-    return {x, y, z};
-}
-DEV f3 rand_in_unit_sphere(Rng& r) {  // vec3_helpers.rs:25-31
-    f3 p = rand_range3(r, -1.0f, 1.0f);
-    while (dot3(p, p) >= 1.0f) p = rand_range3(r, -1.0f, 1.0f);
-    return p;
-}
-
-// ---- primitives ---------------------------------------------------------------
-struct Hit {
-    float t;
-    uint32_t prim;  // index into prims[], HIT_NONE, or HIT_MEDIUM_BIT | group
-    int grp;        // instance group of the hit primitive, or -1
-    uint32_t key;   // tie key: caller id of the primitive, MEDIUM_KEY_BASE + k for media
+struct PathRegs {
+    f3 o, d, T;
+    float time;
+    uint32_t k0, k1, meta, slot;  // meta = bounce << 24 | rng counter
 };
 
-DEV f3 moving_center(const Scene& S, f3 c0, uint32_t aux, float time) {  // shapes.rs:189-191
-    const float4* mp = reinterpret_cast<const float4*>(S.moving + aux);
-    float4 m0 = mp[0], m1 = mp[1];
-    f3 c1{m0.x, m0.y, m0.z};
-    float t0 = m0.w, t1 = m1.x;
-    return c0 + (((time - t0) / (t1 - t0)) * (c1 - c0));
-}
-
-// Candidate t of one primitive in [tmin, tmax] (inclusive, as the reference's "< t_min || > t_max" rejects).
-DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out,
-                        uint32_t& id_out) {
-    const float4* pp = reinterpret_cast<const float4*>(S.prims + pi);
-    float4 A = pp[0];
-    float4 B = pp[1];
-    uint32_t info = __float_as_uint(B.y);
-    id_out = __float_as_uint(B.z);
-    uint32_t kind = info & 7u;
-    float t;
-    if (kind <= PK_MOVING_SPHERE) {  // shapes.rs:117-139, 195-217
-        f3 c{A.x, A.y, A.z};
-        if (kind == PK_MOVING_SPHERE) c = moving_center(S, c, __float_as_uint(B.w), time);
-        float r = A.w;
-        f3 oc = o - c;
-        float half_b = dot3(oc, d);
-        float cc = dot3(oc, oc) - r * r;
-        float disc = half_b * half_b - a * cc;
-        if (disc < 0.0f) return false;
-        float sq = __builtin_sqrtf(disc);
-        t = (-half_b - sq) / a;
-        if (t < tmin || t > tmax) {
-            t = (-half_b + sq) / a;
-            if (t < tmin || t > tmax) return false;
-        }
-    } else {  // shapes.rs:279-292, 343-356, 407-420
-        int ax = kind == PK_RECT_XY ? 2 : (kind == PK_RECT_XZ ? 1 : 0);
-        int a0 = ax == 0 ? 1 : 0;
-        int a1 = ax == 2 ? 1 : 2;
-        t = (A.x - comp(o, ax)) / comp(d, ax);
-        if (t < tmin || t > tmax) return false;
-        float x = comp(o, a0) + t * comp(d, a0);
-        float y = comp(o, a1) + t * comp(d, a1);
-        if (x < A.y || x > A.w || y < A.z || y > B.x) return false;
-    }
-    t_out = t;
-    return true;
-}
-
-// Closest-hit update with the exact-tie rule "higher id wins" (scene.rs:32-38: the later shape wins).
-DEV void test_prim(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time, float tmin, int grp, Hit& best) {
-    float t;
-    uint32_t id;
-    if (!prim_candidate(S, pi, o, d, a, time, tmin, best.t, t, id)) return;
-    if (t == best.t && best.prim != HIT_NONE && id < best.key) return;
-    best.t = t;
-    best.prim = pi;
-    best.grp = grp;
-    best.key = id;
-}
-
-// Scene::intersect over a short primitive list (scene.rs:27-41); only t is needed by the medium.
-DEV bool list_closest(const Scene& S, uint32_t ref, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out) {
-    uint32_t first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 15u) + 1u;
-    float closest = tmax;
-    bool any = false;
-    for (uint32_t i = 0; i < cnt; i++) {
-        float t;
-        uint32_t id;
-        if (prim_candidate(S, first + i, o, d, a, time, tmin, closest, t, id)) {
-            closest = t;
-            any = true;
-        }
-    }
-    t_out = closest;
-    return any;
-}
-
-// ConstantMedium::intersect (shapes.rs:648-701).  wo/wd: the world ray.  A medium that reports a hit
-// replaces the closest hit so far unchecked, as Scene::intersect does (scene.rs:33-37): its final_t may
-// lie beyond best.t because shapes.rs:676-683 divides by the ray length twice.
-DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1,
-                     uint32_t bounce, Hit& best) {
-    const Group& G = S.groups[g];
-    f3 o = wo, d = wd;
-    if (G.has_xform) {  // TransformedObject as the boundary (shapes.rs:66-70); t is shared between spaces
-        o = xf_point(G.minv, wo);
-        d = xf_vector(G.minv, wd);
-    }
-    float a = dot3(d, d);
-    float r1, r2;
-    if (!list_closest(S, G.root_ref, o, d, a, time, -INF_F, INF_F, r1)) return;
-    if (!list_closest(S, G.root_ref, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
-    if (r1 < tmin) r1 = tmin;
-    if (r2 > best.t) r2 = best.t;
-    if (r1 >= r2) return;
-    if (r1 < 0.0f) r1 = 0.0f;
-    double len = (double)len3(wd);
-    double inside = (double)(r2 - r1) / len;
-    double xi = medium_xi(k0, k1, bounce, G.order);
-    double hit_distance = G.neg_inv_density * log(xi);
-    if (hit_distance > inside) return;
-    best.t = r1 + (float)(hit_distance / len);
-    best.prim = HIT_MEDIUM_BIT | g;
-    best.grp = -1;
-    best.key = MEDIUM_KEY_BASE + G.order;
-}
-
-DEV float pad_up(float x) { return x + __builtin_fabsf(x) * 6e-7f; }
-DEV float pad_down(float x) { return x - __builtin_fabsf(x) * 6e-7f; }
-DEV f3 fast_rcp3(f3 d) { return {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)}; }
-
-// Conservative slab test: entry distance in tn; true when [tn, tf] overlaps [tmin, tbest] after padding.
-// fminf/fmaxf ignore NaN (0 * inf when a direction component is zero and the origin lies on a slab plane).
-DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tmin, float tbest, float& tn) {
-    float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
-    float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
-    float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
-    float n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-    float f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    tn = n;
-    float fp = pad_up(f);
-    return (pad_down(n) <= fp) && (fp >= tmin) && (pad_down(n) <= tbest);
-}
-
-// Short-stack traversal of the two-level BVH.  stk points at this lane's column of the LDS stack;
-// consecutive entries are STRIDE words apart so that the 64 lanes of a wave hit 64 different banks.
-struct TraceCount {
-    uint32_t nodes, prims;  // inner nodes fetched, primitive records tested (instrumented builds only)
-};
-template <int STRIDE, int STACK, bool GROUPS, bool COUNT = false>
-DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
-                   uint32_t bounce, Hit& best, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
-    best.t = tmax;
-    best.prim = HIT_NONE;
-    best.grp = -1;
-    best.key = 0;
-    uint32_t cur = S.root_ref;
-    f3 o = wo, d = wd;
-    float a = dot3(d, d);
-    f3 inv = fast_rcp3(d);
-    int grp = -1;
-    int sp = 0;
-    if (cur == REF_EMPTY) goto surfaces_done;
+// Jitter + Camera::get_ray for path slot `slot` of the batch (main.rs:471-474, camera.rs:54-65).
+// slot = sample_local * npix + pixel_local: neighbouring lanes are neighbouring pixels of one tile.
+DEV void camera_path(const rtk::RenderConst& rc, const rtk::Batch& b, uint32_t slot, PathRegs& p) {
+    uint32_t pl = slot % b.npix;
+    uint32_t sample = b.sample0 + slot / b.npix;
+    uint32_t pixel = b.pixel_list[pl];
+    uint32_t i = pixel % rc.width, j = pixel / rc.width;
+    Rng rng;
+    stream_key(rc.seed, pixel, sample, rng.k0, rng.k1);
+    rng.n = 0;
+    float u = ((float)i + rng.f32()) / (float)(rc.width - 1);
+    float v = ((float)(rc.height - 1 - j) + rng.f32()) / (float)(rc.height - 1);
+    // vec3_helpers.rs:47-60: the first point with |p|^2 >= 1 (sic), drawn even when the aperture is 0
+    float px, py;
     for (;;) {
-        uint32_t type = cur >> 30;
-        bool descend = false;
-        if (type == REF_INNER) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            if (COUNT) cnt->nodes++;
-            float tn0, tn1;
-            bool h0 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, tn0);
-            bool h1 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv, tmin, best.t, tn1);
-            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-            h0 = h0 && (c0 != REF_EMPTY);
-            h1 = h1 && (c1 != REF_EMPTY);
-            if (h0 && h1) {
-                uint32_t nearc = c0, farc = c1;
-                if (tn1 < tn0) {
-                    nearc = c1;
-                    farc = c0;
-                }
-                if (sp < STACK) {
-                    stk[sp * STRIDE] = farc;
-                    sp++;
-                } else {
-                    *overflow_flag = 1u;
-                }
-                cur = nearc;
-                descend = true;
-            } else if (h0) {
-                cur = c0;
-                descend = true;
-            } else if (h1) {
-                cur = c1;
-                descend = true;
-            }
-        } else if (type == REF_PRIMS) {
-            uint32_t first = cur & 0x03FFFFFFu, n_leaf = ((cur >> 26) & 15u) + 1u;
-            for (uint32_t i = 0; i < n_leaf; i++) test_prim(S, first + i, o, d, a, time, tmin, grp, best);
-            if (COUNT) cnt->prims += n_leaf;
-        } else if (GROUPS && type == REF_INSTANCE) {
-            uint32_t g = cur & 0x3FFFFFFFu;
-            const Group& G = S.groups[g];
-            uint32_t root = G.root_ref;
-            if (root != REF_EMPTY) {
-                if (G.has_xform) {  // shapes.rs:66-70
-                    o = xf_point(G.minv, wo);
-                    d = xf_vector(G.minv, wd);
-                    a = dot3(d, d);
-                    inv = fast_rcp3(d);
-                }
-                if (sp < STACK) {
-                    stk[sp * STRIDE] = REF_SENTINEL;
-                    sp++;
-                    grp = (int)g;
-                    cur = root;
-                    descend = true;
-                } else {
-                    *overflow_flag = 1u;
-                    o = wo;
-                    d = wd;
-                    a = dot3(d, d);
-                    inv = fast_rcp3(d);
-                }
-            }
-        }
-        if (descend) continue;
-        for (;;) {  // pop
-            if (sp == 0) goto surfaces_done;
-            sp--;
-            cur = stk[sp * STRIDE];
-            if (cur != REF_SENTINEL) break;
-            o = wo;
-            d = wd;
-            a = dot3(d, d);
-            inv = fast_rcp3(d);
-            grp = -1;
-        }
+        px = rng.range(-1.0f, 1.0f);
+        py = rng.range(-1.0f, 1.0f);
+        if ((px * px + py * py) + 0.0f * 0.0f >= 1.0f) break;
     }
-surfaces_done:
-    // media come after all surfaces, in creation order (the order of a Scene whose media were added last)
-    if (GROUPS)
-        for (uint32_t m = 0; m < S.n_media; m++) {
-            test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
-            if (COUNT) cnt->prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);  // two boundary queries
-        }
+    float rdx = rc.cam.lens_radius * px, rdy = rc.cam.lens_radius * py;
+    f3 offset = ld3(rc.cam.u) * rdx + ld3(rc.cam.v) * rdy;
+    p.o = ld3(rc.cam.origin) + offset;
+    p.d = ld3(rc.cam.llc) + u * ld3(rc.cam.horizontal) + v * ld3(rc.cam.vertical) - ld3(rc.cam.origin) - offset;
+    p.time = rng.range(rc.cam.time_start, rc.cam.time_end);
+    p.T = {1.0f, 1.0f, 1.0f};
+    p.k0 = rng.k0;
+    p.k1 = rng.k1;
+    p.meta = rng.n & 0x00FFFFFFu;
+    p.slot = slot;
 }
 
-// ---- hit record (hit_record.rs, shapes.rs) --------------------------------------
-struct Record {
-    f3 point, normal;
-    float u, v;
-    bool front;
-    uint32_t mat;
-};
-DEV void sphere_uv(f3 p, float& u, float& v) {  // shapes.rs:19-24
-    float theta = acosf(-p.y);
-    float phi = atan2f(-p.z, p.x) + PI_F;
-    u = phi / (2.0f * PI_F);
-    v = theta / PI_F;
+DEV void load_path(const rtk::PathState& st, uint32_t idx, PathRegs& p) {
+    float4 ot = st.o_time[idx], ds = st.d_slot[idx], tm = st.thr_meta[idx];
+    uint2 key = st.key[idx];
+    p.o = {ot.x, ot.y, ot.z};
+    p.time = ot.w;
+    p.d = {ds.x, ds.y, ds.z};
+    p.slot = __float_as_uint(ds.w);
+    p.T = {tm.x, tm.y, tm.z};
+    p.meta = __float_as_uint(tm.w);
+    p.k0 = key.x;
+    p.k1 = key.y;
 }
-template <bool WANT_UV>
-DEV void make_record(const Scene& S, f3 wo, f3 wd, float time, const Hit& h, Record& rec) {
-    if (h.prim & HIT_MEDIUM_BIT) {  // shapes.rs:690-697
-        const Group& G = S.groups[h.prim & 0x3FFFFFFFu];
-        rec.point = wo + (h.t * wd);
-        rec.normal = {1.0f, 0.0f, 0.0f};
-        rec.front = true;
-        rec.u = 0.0f;
-        rec.v = 0.0f;
-        rec.mat = G.mat;
-        return;
-    }
-    f3 o = wo, d = wd;
-    const Group* G = nullptr;
-    if (h.grp >= 0) {
-        G = S.groups + h.grp;
-        if (G->has_xform) {
-            o = xf_point(G->minv, wo);
-            d = xf_vector(G->minv, wd);
-        } else {
-            G = nullptr;
-        }
-    }
-    const float4* pp = reinterpret_cast<const float4*>(S.prims + h.prim);
-    float4 A = pp[0], B = pp[1];
-    uint32_t info = __float_as_uint(B.y);
-    uint32_t kind = info & 7u;
-    rec.mat = info >> 8;
-    f3 point = o + (h.t * d);
-    f3 outward;
-    rec.u = 0.0f;
-    rec.v = 0.0f;
-    if (kind <= PK_MOVING_SPHERE) {  // shapes.rs:141-153
-        f3 c{A.x, A.y, A.z};
-        if (kind == PK_MOVING_SPHERE) c = moving_center(S, c, __float_as_uint(B.w), time);
-        outward = (point - c) / A.w;
-        if (WANT_UV) sphere_uv(outward, rec.u, rec.v);
-    } else {  // shapes.rs:294-303
-        int ax = kind == PK_RECT_XY ? 2 : (kind == PK_RECT_XZ ? 1 : 0);
-        int a0 = ax == 0 ? 1 : 0;
-        int a1 = ax == 2 ? 1 : 2;
-        outward = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f};
-        if (WANT_UV) {
-            rec.u = (comp(point, a0) - A.y) / (A.w - A.y);
-            rec.v = (comp(point, a1) - A.z) / (B.x - A.z);
-        }
-    }
-    bool front = dot3(d, outward) < 0.0f;  // hit_record.rs:32-42
-    f3 normal = front ? outward : -outward;
-    if (G) {  // shapes.rs:74-88: normal through M (not its inverse transpose), then face-set again
-        f3 nw = normalize3(xf_vector(G->m, normal));
-        point = xf_point(G->m, point);
-        front = dot3(wd, nw) < 0.0f;
-        normal = front ? nw : -nw;
-    }
-    rec.point = point;
-    rec.normal = normal;
-    rec.front = front;
+DEV void store_path(const rtk::PathState& st, uint32_t idx, const PathRegs& p) {
+    st.o_time[idx] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
+    st.d_slot[idx] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(p.slot));
+    st.thr_meta[idx] = make_float4(p.T.x, p.T.y, p.T.z, __uint_as_float(p.meta));
+    st.key[idx] = make_uint2(p.k0, p.k1);
 }
 
-// ---- textures (texture.rs, perlin.rs) -------------------------------------------
-DEV float perlin_noise(const PerlinTable& P, f3 p) {  // perlin.rs:46-88
-    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
-    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
-    int i = (int)fx, j = (int)fy, k = (int)fz;
-    float uu = u * u * (3.0f - 2.0f * u);
-    float vv = v * v * (3.0f - 2.0f * v);
-    float ww = w * w * (3.0f - 2.0f * w);
-    float acc = 0.0f;
-#pragma unroll
-    for (int di = 0; di < 2; di++)
-#pragma unroll
-        for (int dj = 0; dj < 2; dj++)
-#pragma unroll
-            for (int dk = 0; dk < 2; dk++) {
-                int idx = P.perm[0][(uint32_t)(i + di) & 255u] ^ P.perm[1][(uint32_t)(j + dj) & 255u] ^
-                          P.perm[2][(uint32_t)(k + dk) & 255u];
-                const float4 c4 = *reinterpret_cast<const float4*>(P.vec[idx & 255]);
-                f3 c{c4.x, c4.y, c4.z};
-                f3 weight{u - (float)di, v - (float)dj, w - (float)dk};
-                float wu = di ? uu : (1.0f - uu);
-                float wv = dj ? vv : (1.0f - vv);
-                float wwv = dk ? ww : (1.0f - ww);
-                acc += wu * wv * wwv * dot3(weight, c);
-            }
-    return acc;
-}
-DEV float perlin_turb(const PerlinTable& P, f3 p, int depth) {  // perlin.rs:90-102
-    float acc = 0.0f;
-    f3 temp = p;
-    float weight = 1.0f;
-    for (int i = 0; i < depth; i++) {
-        acc += weight * perlin_noise(P, temp);
-        weight *= 0.5f;
-        temp = 2.0f * temp;
+// One step of ray_color (main.rs:44-63) after the hit is known.  Returns true when the path goes on (p is
+// then the scattered ray with the updated throughput); otherwise its radiance has been written.
+DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, const Hit& h, float4* __restrict__ radiance) {
+    if (h.prim == HIT_NONE) {  // main.rs:60-62
+        f3 L = p.T * ld3(rc.background);
+        radiance[p.slot] = make_float4(L.x, L.y, L.z, 0.0f);
+        return false;
     }
-    return __builtin_fabsf(acc);
-}
-DEV float rust_clamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
-DEV uint32_t rust_as_u32(float f) {  // saturating, NaN -> 0
-    if (!(f == f)) return 0u;
-    if (f <= 0.0f) return 0u;
-    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
-    return (uint32_t)f;
-}
-DEV bool tex_needs_uv(const Scene& S, uint32_t ti) {
-    Texture t = S.texs[ti];
-    return t.kind == TK_IMAGE || t.kind == TK_CHECKER;  // a checker may nest an image
-}
-DEV f3 tex_value(const Scene& S, uint32_t ti, float u, float v, f3 p) {
-    const float4* tp = reinterpret_cast<const float4*>(S.texs + ti);
-    float4 T0 = tp[0], T1 = tp[1];
-    uint32_t kind = __float_as_uint(T0.x);
-    for (int it = 0; it < 8 && kind == TK_CHECKER; it++) {  // texture.rs:52-62
-        float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
-        ti = sines < 0.0f ? __float_as_uint(T1.x) : __float_as_uint(T1.y);
-        tp = reinterpret_cast<const float4*>(S.texs + ti);
-        T0 = tp[0];
-        T1 = tp[1];
-        kind = __float_as_uint(T0.x);
-    }
-    if (kind == TK_NOISE) {  // texture.rs:78-82
-        const PerlinTable& P = S.perlin[__float_as_uint(T1.w)];
-        float s = 1.0f + sinf(T1.z * p.z + 10.0f * perlin_turb(P, p, 7));
-        return {0.5f * s, 0.5f * s, 0.5f * s};
-    }
-    if (kind == TK_IMAGE) {  // texture.rs:96-117
-        const Image im = S.images[__float_as_uint(T1.w)];
-        float cu = rust_clamp(u, 0.0f, 1.0f);
-        float cv = 1.0f - rust_clamp(v, 0.0f, 1.0f);
-        uint32_t i = rust_as_u32(cu * (float)im.w);
-        uint32_t j = rust_as_u32(cv * (float)im.h);
-        if (i >= im.w) i = im.w - 1;
-        if (j >= im.h) j = im.h - 1;
-        const uint8_t* px = im.rgb + 3ull * ((unsigned long long)j * im.w + i);
-        return {(float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f};
-    }
-    return {T0.y, T0.z, T0.w};  // texture.rs:18-22
-}
-
-// ---- materials (materials.rs, vec3_helpers.rs) ------------------------------------
-DEV f3 reflect3(f3 v, f3 n) {  // vec3_helpers.rs:62-66
-    float scalar = 2.0f * dot3(v, n);
-    return v - scalar * n;
-}
-DEV f3 refract3(f3 uv, f3 n, float ratio) {  // vec3_helpers.rs:68-75
-    float dot_p = dot3(n, -uv);
-    float cos_theta = fminf(dot_p, 1.0f);
-    f3 perp = ratio * (uv + cos_theta * n);
-    f3 par = (-__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)))) * n;
-    return perp + par;
-}
-DEV float reflectance(float cosine, float ref_index) {  // materials.rs:109-114
-    float r0 = (1.0f - ref_index) / (1.0f + ref_index);
-    r0 = r0 * r0;
-    return r0 + (1.0f - r0) * powf(1.0f - cosine, 5.0f);
-}
-// returns true when the path continues; att and the scattered direction are set then
-DEV bool scatter(const Scene& S, const Material& M, f3 wd, const Record& rec, Rng& rng, f3& att, f3& dir) {
-    switch (M.kind) {
-        case MK_LAMBERTIAN: {  // materials.rs:45-61
-            f3 sc = rec.normal + normalize3(rand_in_unit_sphere(rng));
-            if (__builtin_fabsf(sc.x) < F32_EPSILON && __builtin_fabsf(sc.y) < F32_EPSILON && __builtin_fabsf(sc.z) < F32_EPSILON)
-                sc = rec.normal;
-            dir = sc;
-            att = tex_value(S, M.tex, rec.u, rec.v, rec.point);
-            return true;
-        }
-        case MK_METAL: {  // materials.rs:84-95 (draws even when fuzz == 0)
-            f3 reflected = reflect3(normalize3(wd), rec.normal);
-            dir = reflected + M.fuzz * rand_in_unit_sphere(rng);
-            att = ld3(M.albedo);
-            return dot3(dir, rec.normal) > 0.0f;
-        }
-        case MK_DIELECTRIC: {  // materials.rs:117-148
-            att = {1.0f, 1.0f, 1.0f};
-            float ratio = rec.front ? 1.0f / M.ior : M.ior;
-            f3 unit = normalize3(wd);
-            float cos_theta = fminf(dot3(rec.normal, -unit), 1.0f);
-            float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
-            bool cannot_refract = ratio * sin_theta > 1.0f;
-            if (cannot_refract || reflectance(cos_theta, ratio) > rng.f32())
-                dir = reflect3(unit, rec.normal);
-            else
-                dir = refract3(unit, rec.normal, ratio);
-            return true;
-        }
-        case MK_ISOTROPIC: {  // materials.rs:204-215
-            dir = normalize3(rand_in_unit_sphere(rng));
-            att = tex_value(S, M.tex, rec.u, rec.v, rec.point);
-            return true;
-        }
-        default:  // MK_LIGHT, materials.rs:176-179
+    // material first, so that uv (acos/atan2) is only evaluated for textures that read it
+    uint32_t mi;
+    if (h.prim & HIT_MEDIUM_BIT)
+        mi = S.groups[h.prim & 0x3FFFFFFFu].mat;
+    else
+        mi = __float_as_uint(reinterpret_cast<const float4*>(S.prims + h.prim)[1].y) >> 8;
+    const Material M = load_material(S, mi);
+    Record rec;
+    if (material_needs_uv(S, M))
+        make_record<true>(S, p.o, p.d, p.time, h, rec);
+    else
+        make_record<false>(S, p.o, p.d, p.time, h, rec);
+    const uint32_t bounce = p.meta >> 24;
+    Rng rng{p.k0, p.k1, p.meta & 0x00FFFFFFu};
+    f3 att{1.0f, 1.0f, 1.0f}, dir{0.0f, 0.0f, 0.0f};
+    if (scatter(S, M, p.d, rec, rng, att, dir)) {
+        if (bounce + 1u >= rc.max_depth) {  // main.rs:45-47: the next ray_color call returns zero
+            radiance[p.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             return false;
-    }
-}
-
-DEV Material load_material(const Scene& S, uint32_t mi) {
-    const float4* mp = reinterpret_cast<const float4*>(S.mats + mi);
-    float4 m0 = mp[0], m1 = mp[1];
-    Material M;
-    M.kind = __float_as_uint(m0.x);
-    M.tex = __float_as_uint(m0.y);
-    M.albedo[0] = m0.z;
-    M.albedo[1] = m0.w;
-    M.albedo[2] = m1.x;
-    M.fuzz = m1.y;
-    M.ior = m1.z;
-    M.pad = 0;
-    return M;
-}
-DEV bool material_needs_uv(const Scene& S, const Material& M) {
-    if (M.kind == MK_METAL || M.kind == MK_DIELECTRIC) return false;
-    return tex_needs_uv(S, M.tex);
-}
-
-DEV uint32_t lane_prefix(unsigned long long mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-// =================================================================================
-// Kernels
-// =================================================================================
-
-// One thread per path slot.  slot = sample_local * npix_batch + pixel_local, so neighbouring lanes are
-// neighbouring pixels of one tile (coherent camera rays) and k_accumulate reads radiance coalesced.
-__global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, const uint32_t* __restrict__ pixel_list,
-                                                        uint32_t npix_batch, uint32_t sample0, uint32_t n_samples,
-                                                        rtk::PathState out, uint32_t* counts) {
-    const uint32_t n = npix_batch * n_samples;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        counts[0] = n;
-        counts[1] = 0;
-    }
-    for (uint32_t slot = blockIdx.x * rtk::BLOCK + threadIdx.x; slot < n; slot += gridDim.x * rtk::BLOCK) {
-        uint32_t pl = slot % npix_batch;
-        uint32_t sample = sample0 + slot / npix_batch;
-        uint32_t pixel = pixel_list[pl];
-        uint32_t i = pixel % rc.width, j = pixel / rc.width;
-        Rng rng;
-        stream_key(rc.seed, pixel, sample, rng.k0, rng.k1);
-        rng.n = 0;
-        // main.rs:471-472
-        float u = ((float)i + rng.f32()) / (float)(rc.width - 1);
-        float v = ((float)(rc.height - 1 - j) + rng.f32()) / (float)(rc.height - 1);
-        // camera.rs:54-65 ; vec3_helpers.rs:47-60 (first point with |p|^2 >= 1)
-        float px, py;
-        for (;;) {
-            px = rng.range(-1.0f, 1.0f);
-            py = rng.range(-1.0f, 1.0f);
-            if ((px * px + py * py) + 0.0f * 0.0f >= 1.0f) break;
         }
-        float rdx = rc.cam.lens_radius * px, rdy = rc.cam.lens_radius * py;
-        f3 offset = ld3(rc.cam.u) * rdx + ld3(rc.cam.v) * rdy;
-        f3 origin = ld3(rc.cam.origin) + offset;
-        f3 dir = ld3(rc.cam.llc) + u * ld3(rc.cam.horizontal) + v * ld3(rc.cam.vertical) - ld3(rc.cam.origin) - offset;
-        float time = rng.range(rc.cam.time_start, rc.cam.time_end);
-        out.o_time[slot] = make_float4(origin.x, origin.y, origin.z, time);
-        out.d_slot[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(slot));
-        out.thr_meta[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.n & 0x00FFFFFFu));
-        out.key[slot] = make_uint2(rng.k0, rng.k1);
+        p.T = p.T * att;
+        p.o = rec.point;
+        p.d = dir;
+        p.meta = ((bounce + 1u) << 24) | (rng.n & 0x00FFFFFFu);
+        return true;
+    }
+    f3 E{0.0f, 0.0f, 0.0f};  // main.rs:57-59
+    if (M.kind == MK_LIGHT) E = tex_value(S, M.tex, rec.u, rec.v, rec.point);
+    f3 L = p.T * E;
+    radiance[p.slot] = make_float4(L.x, L.y, L.z, 0.0f);
+    return false;
+}
+
+// Block-wide compaction of the survivors into queue `shard` of `out`: wave ballot + prefix, one atomic per
+// block.  Must be reached by every thread of the block; `parity` alternates between consecutive calls.
+struct CompactLds {
+    uint32_t wave_tot[2][rtk::BLOCK / 64];
+    uint32_t block_base[2];
+};
+DEV void compact_store(CompactLds& lds, uint32_t parity, bool alive, const PathRegs& p, const rtk::PathState& out,
+                       uint32_t* out_count, uint32_t shard_base) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long mask = __ballot(alive);
+    uint32_t prefix = lane_prefix(mask);
+    if (lane == 0) lds.wave_tot[parity][wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < rtk::BLOCK / 64; w++) tot += lds.wave_tot[parity][w];
+        lds.block_base[parity] = tot ? atomicAdd(out_count, tot) : 0u;
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t off = lds.block_base[parity] + prefix;
+        for (uint32_t w = 0; w < wave; w++) off += lds.wave_tot[parity][w];
+        store_path(out, shard_base + off, p);
+    }
+}
+
+// slots of a batch of n paths that fall into shard s (tiles of BLOCK slots are dealt round-robin)
+DEV uint32_t primary_count(uint32_t n, uint32_t s) {
+    uint32_t tiles = (n + rtk::BLOCK - 1) / rtk::BLOCK;
+    uint32_t nt = tiles / rtk::NSHARD + (s < tiles % rtk::NSHARD ? 1u : 0u);
+    uint32_t cnt = nt * rtk::BLOCK;
+    uint32_t rem = n % rtk::BLOCK;
+    if (rem && nt && (tiles - 1) % rtk::NSHARD == s) cnt -= rtk::BLOCK - rem;
+    return cnt;
+}
+
+// =================================================================================
+// Kernels.  Grid = NSHARD * blocks_per_shard; block b serves shard b % NSHARD.
+// =================================================================================
+
+template <int STACK, bool GROUPS, bool COUNT, bool PRIMARY>
+__global__ __launch_bounds__(rtk::BLOCK) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
+                                                        rtk::PathState out, rtk::Queues q, uint32_t bounce,
+                                                        float4* __restrict__ radiance, unsigned long long* stats,
+                                                        uint32_t* overflow_flag) {
+    __shared__ uint32_t stack[STACK * rtk::BLOCK];
+    __shared__ CompactLds clds;
+    const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
+    const uint32_t n_batch = batch.npix * batch.n_samples;
+    const uint32_t n = PRIMARY ? primary_count(n_batch, shard) : q.counts[(bounce % 3u) * rtk::NSHARD + shard];
+    uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
+    const uint32_t shard_base = shard * q.cap_shard;
+    if (j0 == 0 && threadIdx.x == 0) {
+        q.counts[((bounce + 2u) % 3u) * rtk::NSHARD + shard] = 0;  // the next bounce appends there
+        if (n) atomicAdd(stats, (unsigned long long)n);
+    }
+    uint32_t* stk = stack + threadIdx.x;
+    TraceCount tc{0u, 0u};
+    uint32_t parity = 0;
+    for (uint32_t base = j0 * rtk::BLOCK; base < n; base += stride * rtk::BLOCK, parity ^= 1u) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        PathRegs p;
+        if (i < n) {
+            if (PRIMARY)
+                camera_path(rc, batch, ((base / rtk::BLOCK) * rtk::NSHARD + shard) * rtk::BLOCK + threadIdx.x, p);
+            else
+                load_path(in, shard_base + i, p);
+            Hit h;
+            trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, p.meta >> 24, h, stk,
+                                                        overflow_flag, &tc);
+            alive = shade_path(S, rc, p, h, radiance);
+        }
+        compact_store(clds, parity, alive, p, out, out_count, shard_base);
+    }
+    if (COUNT) {
+        if (tc.nodes) atomicAdd(stats + 1, (unsigned long long)tc.nodes);
+        if (tc.prims) atomicAdd(stats + 2, (unsigned long long)tc.prims);
+    }
+}
+
+__global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk::Batch batch, rtk::PathState out, rtk::Queues q) {
+    const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
+    const uint32_t n = primary_count(batch.npix * batch.n_samples, shard);
+    if (j0 == 0 && threadIdx.x == 0) {
+        q.counts[shard] = n;
+        q.counts[rtk::NSHARD + shard] = 0;
+        q.counts[2 * rtk::NSHARD + shard] = 0;
+    }
+    for (uint32_t base = j0 * rtk::BLOCK; base < n; base += stride * rtk::BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        if (i < n) {
+            PathRegs p;
+            camera_path(rc, batch, ((base / rtk::BLOCK) * rtk::NSHARD + shard) * rtk::BLOCK + threadIdx.x, p);
+            store_path(out, shard * q.cap_shard + i, p);
+        }
     }
 }
 
 template <int STACK, bool GROUPS, bool COUNT>
-__global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in, uint32_t* counts, uint32_t which,
-                                                       float4* __restrict__ hits, unsigned long long* rays_total,
+__global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
+                                                       float4* __restrict__ hits, unsigned long long* stats,
                                                        uint32_t* overflow_flag) {
     __shared__ uint32_t stack[STACK * rtk::BLOCK];
-    const uint32_t n = counts[which];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        counts[which ^ 1u] = 0;  // the shade kernel of this bounce appends there
-        atomicAdd(rays_total, (unsigned long long)n);
+    const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
+    const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
+    const uint32_t shard_base = shard * q.cap_shard;
+    if (j0 == 0 && threadIdx.x == 0) {
+        q.counts[((bounce + 2u) % 3u) * rtk::NSHARD + shard] = 0;
+        if (n) atomicAdd(stats, (unsigned long long)n);
     }
     uint32_t* stk = stack + threadIdx.x;
     TraceCount tc{0u, 0u};
-    for (uint32_t i = blockIdx.x * rtk::BLOCK + threadIdx.x; i < n; i += gridDim.x * rtk::BLOCK) {
-        float4 ot = in.o_time[i];
-        float4 ds = in.d_slot[i];
-        uint32_t k0 = 0, k1 = 0, bounce = 0;
+    for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
+        const uint32_t idx = shard_base + i;
+        float4 ot = in.o_time[idx];
+        float4 ds = in.d_slot[idx];
+        uint32_t k0 = 0, k1 = 0, b = 0;
         if (GROUPS) {
-            uint2 key = in.key[i];
+            uint2 key = in.key[idx];
             k0 = key.x;
             k1 = key.y;
-            bounce = __float_as_uint(in.thr_meta[i].w) >> 24;
+            b = __float_as_uint(in.thr_meta[idx].w) >> 24;
         }
         Hit h;
         trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, k0,
-                                                    k1, bounce, h, stk, overflow_flag, &tc);
-        hits[i] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), 0.0f);
+                                                    k1, b, h, stk, overflow_flag, &tc);
+        hits[idx] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), 0.0f);
     }
-    if (COUNT) {  // rays_total[1] = inner nodes fetched, rays_total[2] = primitive records tested
-        if (tc.nodes) atomicAdd(rays_total + 1, (unsigned long long)tc.nodes);
-        if (tc.prims) atomicAdd(rays_total + 2, (unsigned long long)tc.prims);
+    if (COUNT) {
+        if (tc.nodes) atomicAdd(stats + 1, (unsigned long long)tc.nodes);
+        if (tc.prims) atomicAdd(stats + 2, (unsigned long long)tc.prims);
     }
 }
 
 __global__ __launch_bounds__(rtk::BLOCK) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
-                                                       const float4* __restrict__ hits, uint32_t* counts, uint32_t which,
+                                                       const float4* __restrict__ hits, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ radiance) {
-    __shared__ uint32_t wave_tot[2][rtk::BLOCK / 64];
-    __shared__ uint32_t block_base[2];
-    const uint32_t n = counts[which];
-    uint32_t* out_count = counts + (which ^ 1u);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __shared__ CompactLds clds;
+    const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
+    const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
+    uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
+    const uint32_t shard_base = shard * q.cap_shard;
     uint32_t parity = 0;
-    for (uint32_t base = blockIdx.x * rtk::BLOCK; base < n; base += gridDim.x * rtk::BLOCK, parity ^= 1u) {
+    for (uint32_t base = j0 * rtk::BLOCK; base < n; base += stride * rtk::BLOCK, parity ^= 1u) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false;
-        float4 o_new, d_new, t_new;
-        uint2 key = make_uint2(0, 0);
+        PathRegs p;
         if (i < n) {
-            float4 ot = in.o_time[i];
-            float4 ds = in.d_slot[i];
-            float4 tm = in.thr_meta[i];
-            key = in.key[i];
-            float4 hv = hits[i];
-            const uint32_t slot = __float_as_uint(ds.w);
-            const uint32_t meta = __float_as_uint(tm.w);
-            const uint32_t bounce = meta >> 24;
-            f3 T{tm.x, tm.y, tm.z};
-            f3 wo{ot.x, ot.y, ot.z}, wd{ds.x, ds.y, ds.z};
+            load_path(in, shard_base + i, p);
+            float4 hv = hits[shard_base + i];
             Hit h;
             h.t = hv.x;
             h.prim = __float_as_uint(hv.y);
             h.grp = __float_as_int(hv.z);
             h.key = 0;
-            if (h.prim == HIT_NONE) {  // main.rs:60-62
-                f3 L = T * ld3(rc.background);
-                radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
-            } else {
-                Record rec;
-                Material M;
-                {
-                    // material index first, so that uv (acos/atan2) is only evaluated for textures that read it
-                    uint32_t mi;
-                    if (h.prim & HIT_MEDIUM_BIT)
-                        mi = S.groups[h.prim & 0x3FFFFFFFu].mat;
-                    else
-                        mi = __float_as_uint(reinterpret_cast<const float4*>(S.prims + h.prim)[1].y) >> 8;
-                    M = load_material(S, mi);
-                }
-                if (material_needs_uv(S, M))
-                    make_record<true>(S, wo, wd, ot.w, h, rec);
-                else
-                    make_record<false>(S, wo, wd, ot.w, h, rec);
-                Rng rng{key.x, key.y, meta & 0x00FFFFFFu};
-                f3 att{1.0f, 1.0f, 1.0f}, dir{0.0f, 0.0f, 0.0f};
-                if (scatter(S, M, wd, rec, rng, att, dir)) {
-                    if (bounce + 1u >= rc.max_depth) {  // main.rs:45-47: the next ray_color call returns zero
-                        radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    } else {
-                        alive = true;
-                        f3 Tn = T * att;
-                        o_new = make_float4(rec.point.x, rec.point.y, rec.point.z, ot.w);
-                        d_new = make_float4(dir.x, dir.y, dir.z, ds.w);
-                        t_new = make_float4(Tn.x, Tn.y, Tn.z, __uint_as_float(((bounce + 1u) << 24) | (rng.n & 0x00FFFFFFu)));
-                    }
-                } else {  // main.rs:57-59
-                    f3 E{0.0f, 0.0f, 0.0f};
-                    if (M.kind == MK_LIGHT) E = tex_value(S, M.tex, rec.u, rec.v, rec.point);
-                    f3 L = T * E;
-                    radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
-                }
-            }
+            alive = shade_path(S, rc, p, h, radiance);
         }
-        // compaction: wave ballot + prefix, one atomic per block
-        unsigned long long mask = __ballot(alive);
-        uint32_t prefix = lane_prefix(mask);
-        if (lane == 0) wave_tot[parity][wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < rtk::BLOCK / 64; w++) tot += wave_tot[parity][w];
-            block_base[parity] = tot ? atomicAdd(out_count, tot) : 0u;
-        }
-        __syncthreads();
-        if (alive) {
-            uint32_t off = block_base[parity] + prefix;
-            for (uint32_t w = 0; w < wave; w++) off += wave_tot[parity][w];
-            out.o_time[off] = o_new;
-            out.d_slot[off] = d_new;
-            out.thr_meta[off] = t_new;
-            out.key[off] = key;
-        }
+        compact_store(clds, parity, alive, p, out, out_count, shard_base);
     }
 }
 
 // accum[pixel] += radiance of each sample, in sample order (main.rs:478: reduce(|c, src| c + src))
-__global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restrict__ radiance,
-                                                            const uint32_t* __restrict__ pixel_list, uint32_t npix_batch,
-                                                            uint32_t n_samples, float* __restrict__ accum_rgb) {
-    for (uint32_t pl = blockIdx.x * rtk::BLOCK + threadIdx.x; pl < npix_batch; pl += gridDim.x * rtk::BLOCK) {
-        uint32_t pixel = pixel_list[pl];
+__global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restrict__ radiance, rtk::Batch batch,
+                                                            float* __restrict__ accum_rgb) {
+    for (uint32_t pl = blockIdx.x * rtk::BLOCK + threadIdx.x; pl < batch.npix; pl += gridDim.x * rtk::BLOCK) {
+        uint32_t pixel = batch.pixel_list[pl];
         float* a = accum_rgb + 3ull * pixel;
         float r = a[0], g = a[1], b = a[2];
-        for (uint32_t s = 0; s < n_samples; s++) {
-            float4 L = radiance[(unsigned long long)s * npix_batch + pl];
+        for (uint32_t s = 0; s < batch.n_samples; s++) {
+            float4 L = radiance[(unsigned long long)s * batch.npix + pl];
             r = r + L.x;
             g = g + L.y;
             b = b + L.z;
@@ -768,10 +300,10 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_resolve(const float* __restrict_
                                                          uint8_t* __restrict__ out) {
     for (unsigned long long i = (unsigned long long)blockIdx.x * rtk::BLOCK + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * rtk::BLOCK) {
-        float f = sum_rgb[i] * inv;                    // main.rs:481
+        float f = sum_rgb[i] * inv;                      // main.rs:481
         float x = 256.0f * rust_clamp(f, 0.0f, 0.999f);  // main.rs:307-309
-        uint32_t q = rust_as_u32(x);
-        out[i] = (uint8_t)(q > 255u ? 255u : q);
+        uint32_t qv = rust_as_u32(x);
+        out[i] = (uint8_t)(qv > 255u ? 255u : qv);
     }
 }
 
@@ -830,106 +362,118 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
     }
 }
 
-inline int grid_for(unsigned long long n) {
+inline int grid_flat(unsigned long long n) {
     unsigned long long b = (n + rtk::BLOCK - 1) / rtk::BLOCK;
     if (b < 1) b = 1;
-    if (b > (unsigned long long)rtk::MAX_GRID) b = rtk::MAX_GRID;
+    if (b > (unsigned long long)(rtk::NSHARD * rtk::MAX_BLOCKS_PER_SHARD)) b = rtk::NSHARD * rtk::MAX_BLOCKS_PER_SHARD;
     return (int)b;
+}
+inline int grid_sharded(uint32_t blocks_per_shard) {
+    if (blocks_per_shard < 1) blocks_per_shard = 1;
+    if (blocks_per_shard > (uint32_t)rtk::MAX_BLOCKS_PER_SHARD) blocks_per_shard = rtk::MAX_BLOCKS_PER_SHARD;
+    return (int)(blocks_per_shard * rtk::NSHARD);
 }
 
 }  // namespace
 
 namespace rtk {
 
-hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const uint32_t* pixel_list, uint32_t npix_batch,
-                         uint32_t sample0, uint32_t n_samples, PathState out, uint32_t* counts, float4*) {
-    unsigned long long n = (unsigned long long)npix_batch * n_samples;
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(n)), dim3(BLOCK), 0, s, rc, pixel_list, npix_batch, sample0, n_samples, out,
-                       counts);
+// stack size x groups x instrumented -> template instance
+#define RT_DISPATCH_TRACE_CFG(cfg, CALL)                       \
+    do {                                                       \
+        if ((cfg).stack_entries <= 16) {                       \
+            if ((cfg).has_groups) {                            \
+                if ((cfg).count_visits) CALL(16, true, true);  \
+                else CALL(16, true, false);                    \
+            } else {                                           \
+                if ((cfg).count_visits) CALL(16, false, true); \
+                else CALL(16, false, false);                   \
+            }                                                  \
+        } else if ((cfg).stack_entries <= 32) {                \
+            if ((cfg).has_groups) {                            \
+                if ((cfg).count_visits) CALL(32, true, true);  \
+                else CALL(32, true, false);                    \
+            } else {                                           \
+                if ((cfg).count_visits) CALL(32, false, true); \
+                else CALL(32, false, false);                   \
+            }                                                  \
+        } else {                                               \
+            if ((cfg).has_groups) {                            \
+                if ((cfg).count_visits) CALL(64, true, true);  \
+                else CALL(64, true, false);                    \
+            } else {                                           \
+                if ((cfg).count_visits) CALL(64, false, true); \
+                else CALL(64, false, false);                   \
+            }                                                  \
+        }                                                      \
+    } while (0)
+
+hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q) {
+    unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
+    uint32_t bps = (uint32_t)((n + (unsigned long long)BLOCK * NSHARD - 1) / ((unsigned long long)BLOCK * NSHARD));
+    hipLaunchKernelGGL(k_raygen, dim3(grid_sharded(bps)), dim3(BLOCK), 0, s, rc, batch, out, q);
     return hipGetLastError();
 }
 
-template <int STACK, bool COUNT>
-static void launch_trace_t(hipStream_t s, bool groups, int grid, const Scene& scene, PathState in, uint32_t* counts,
-                           uint32_t which, float4* hits, unsigned long long* rays_total, uint32_t* overflow_flag) {
-    if (groups)
-        hipLaunchKernelGGL((k_trace<STACK, true, COUNT>), dim3(grid), dim3(BLOCK), 0, s, scene, in, counts, which, hits,
-                           rays_total, overflow_flag);
-    else
-        hipLaunchKernelGGL((k_trace<STACK, false, COUNT>), dim3(grid), dim3(BLOCK), 0, s, scene, in, counts, which, hits,
-                           rays_total, overflow_flag);
-}
-
-hipError_t launch_trace(hipStream_t s, int stack_entries, bool has_groups, bool count_visits, const Scene& scene,
-                        PathState in, uint32_t* counts, uint32_t which, uint32_t n_bound, float4* hits,
-                        unsigned long long* rays_total, uint32_t* overflow_flag) {
-    int grid = grid_for(n_bound);
-#define RT_TRACE_DISPATCH(N)                                                                                      \
-    do {                                                                                                          \
-        if (count_visits)                                                                                         \
-            launch_trace_t<N, true>(s, has_groups, grid, scene, in, counts, which, hits, rays_total, overflow_flag);  \
-        else                                                                                                      \
-            launch_trace_t<N, false>(s, has_groups, grid, scene, in, counts, which, hits, rays_total, overflow_flag); \
-    } while (0)
-    if (stack_entries <= 16)
-        RT_TRACE_DISPATCH(16);
-    else if (stack_entries <= 32)
-        RT_TRACE_DISPATCH(32);
-    else
-        RT_TRACE_DISPATCH(64);
-#undef RT_TRACE_DISPATCH
+hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, PathState in, Queues q, uint32_t bounce,
+                        uint32_t blocks_per_shard, float4* hits, unsigned long long* stats, uint32_t* overflow_flag) {
+    const dim3 grid(grid_sharded(blocks_per_shard)), block(BLOCK);
+#define RT_CALL(N, G, C) hipLaunchKernelGGL((k_trace<N, G, C>), grid, block, 0, s, scene, in, q, bounce, hits, stats, overflow_flag)
+    RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
+#undef RT_CALL
     return hipGetLastError();
 }
 
 hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc, PathState in, PathState out,
-                        const float4* hits, uint32_t* counts, uint32_t which, uint32_t n_bound, float4* radiance) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_for(n_bound)), dim3(BLOCK), 0, s, scene, rc, in, out, hits, counts, which,
+                        const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance) {
+    hipLaunchKernelGGL(k_shade, dim3(grid_sharded(blocks_per_shard)), dim3(BLOCK), 0, s, scene, rc, in, out, hits, q, bounce,
                        radiance);
     return hipGetLastError();
 }
 
-hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const uint32_t* pixel_list, uint32_t npix_batch,
-                             uint32_t n_samples, float* accum_rgb) {
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(npix_batch)), dim3(BLOCK), 0, s, radiance, pixel_list, npix_batch,
-                       n_samples, accum_rgb);
+hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, const Batch& batch,
+                         PathState in, PathState out, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
+                         unsigned long long* stats, uint32_t* overflow_flag) {
+    const dim3 grid(grid_sharded(blocks_per_shard)), block(BLOCK);
+    if (bounce == 0) {
+#define RT_CALL(N, G, C)                                                                                                    \
+    hipLaunchKernelGGL((k_bounce<N, G, C, true>), grid, block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, \
+                       overflow_flag)
+        RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
+#undef RT_CALL
+    } else {
+#define RT_CALL(N, G, C)                                                                                                     \
+    hipLaunchKernelGGL((k_bounce<N, G, C, false>), grid, block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, \
+                       overflow_flag)
+        RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
+#undef RT_CALL
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, float* accum_rgb) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_flat(batch.npix)), dim3(BLOCK), 0, s, radiance, batch, accum_rgb);
     return hipGetLastError();
 }
 
 hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, uint8_t* out) {
     float inv = 1.0f / (float)spp;  // main.rs:460
-    hipLaunchKernelGGL(k_resolve, dim3(grid_for(n_values)), dim3(BLOCK), 0, s, sum_rgb, (unsigned long long)n_values, inv,
-                       out);
+    hipLaunchKernelGGL(k_resolve, dim3(grid_flat(n_values)), dim3(BLOCK), 0, s, sum_rgb, (unsigned long long)n_values, inv, out);
     return hipGetLastError();
 }
 
-template <int STACK>
-static void launch_ib_t(hipStream_t s, bool groups, int grid, const Scene& scene, uint64_t n, const float* const rays[7],
-                        float tmin, float tmax, uint32_t seed, int32_t* prim, int32_t* inst, float* t, float* normal,
-                        uint8_t* front, float* uv, float* point, uint32_t* overflow_flag) {
-    if (groups)
-        hipLaunchKernelGGL((k_intersect_batch<STACK, true>), dim3(grid), dim3(BLOCK), 0, s, scene, (unsigned long long)n,
-                           rays[0], rays[1], rays[2], rays[3], rays[4], rays[5], rays[6], tmin, tmax, seed, prim, inst, t,
-                           normal, front, uv, point, overflow_flag);
-    else
-        hipLaunchKernelGGL((k_intersect_batch<STACK, false>), dim3(grid), dim3(BLOCK), 0, s, scene, (unsigned long long)n,
-                           rays[0], rays[1], rays[2], rays[3], rays[4], rays[5], rays[6], tmin, tmax, seed, prim, inst, t,
-                           normal, front, uv, point, overflow_flag);
-}
-
-hipError_t launch_intersect_batch(hipStream_t s, int stack_entries, bool has_groups, const Scene& scene, uint64_t n,
-                                  const float* const rays[7], float tmin, float tmax, uint32_t seed, int32_t* prim,
-                                  int32_t* inst, float* t, float* normal, uint8_t* front, float* uv, float* point,
-                                  uint32_t* overflow_flag) {
-    int grid = grid_for(n);
-    if (stack_entries <= 16)
-        launch_ib_t<16>(s, has_groups, grid, scene, n, rays, tmin, tmax, seed, prim, inst, t, normal, front, uv, point,
-                        overflow_flag);
-    else if (stack_entries <= 32)
-        launch_ib_t<32>(s, has_groups, grid, scene, n, rays, tmin, tmax, seed, prim, inst, t, normal, front, uv, point,
-                        overflow_flag);
-    else
-        launch_ib_t<64>(s, has_groups, grid, scene, n, rays, tmin, tmax, seed, prim, inst, t, normal, front, uv, point,
-                        overflow_flag);
+hipError_t launch_intersect_batch(hipStream_t s, const TraceCfg& cfg, const Scene& scene, uint64_t n, const float* const rays[7],
+                                  float tmin, float tmax, uint32_t seed, int32_t* prim, int32_t* inst, float* t, float* normal,
+                                  uint8_t* front, float* uv, float* point, uint32_t* overflow_flag) {
+    const dim3 grid(grid_flat(n)), block(BLOCK);
+    TraceCfg c = cfg;
+    c.count_visits = false;
+#define RT_CALL(N, G, C)                                                                                                      \
+    hipLaunchKernelGGL((k_intersect_batch<N, G>), grid, block, 0, s, scene, (unsigned long long)n, rays[0], rays[1], rays[2], \
+                       rays[3], rays[4], rays[5], rays[6], tmin, tmax, seed, prim, inst, t, normal, front, uv, point,        \
+                       overflow_flag)
+    RT_DISPATCH_TRACE_CFG(c, RT_CALL);
+#undef RT_CALL
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPP
 # every symbol include/rtamd.h declares
 ABI_SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_ctx_set_stream", "rt_ctx_set_max_paths",
-    "rt_ctx_synchronize", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
+    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
     "rt_resolve_u8", "rt_owned_pixels")
@@ -60,7 +60,9 @@ class rt_render_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("batches", C.c_uint32), ("bounce_launches", C.c_uint32),
                 ("render_ms", C.c_double), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
                 ("raygen_ms", C.c_double), ("accumulate_ms", C.c_double), ("trace_launches", C.c_uint64),
-                ("shade_launches", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64)]
+                ("shade_launches", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
+                ("bounce_ms", C.c_double), ("bounce_kernel_launches", C.c_uint64), ("pipeline", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -116,6 +118,7 @@ def core():
     L.rt_ctx_set_stream.argtypes = [vp, vp]
     L.rt_ctx_set_max_paths.argtypes = [vp, u64]
     L.rt_ctx_synchronize.argtypes = [vp]
+    L.rt_ctx_set_pipeline.argtypes = [vp, C.c_int]
     L.rt_scene_clear.argtypes = [vp]
     L.rt_scene_set_spheres.argtypes = [vp, u32] + [vp] * 7
     L.rt_scene_set_rects.argtypes = [vp, u32] + [vp] * 6
@@ -265,6 +268,10 @@ class Context:
     def use_torch_stream(self):
         import torch
         self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def set_pipeline(self, pipeline):
+        """-1 pick per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce)."""
+        self._check(self.L.rt_ctx_set_pipeline(self.h, pipeline))
 
     def synchronize(self):
         self._check(self.L.rt_ctx_synchronize(self.h))

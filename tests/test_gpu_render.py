@@ -237,6 +237,23 @@ def test_rank_split_sample_split_and_batch_size_change_no_bit(gpu_ctx):
     small.close()
 
 
+@pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "two_perlin_spheres"])
+def test_fused_and_split_pipelines_give_the_same_bits(name):
+    w, h, spp = 150, 100, 5
+    ctx = rtamd.Context(0)
+    ctx.load_scene(name, seed=1)
+    cam = ctx.preset_camera(w / h)
+    out = {}
+    for pipe in (0, 1):
+        ctx.set_pipeline(pipe)
+        img, st = ctx.render(w, h, cam, spp, seed=9)
+        assert st["pipeline"] == pipe
+        out[pipe] = (img, st["rays"])
+    ctx.close()
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0])
+
+
 def test_device_and_host_accumulators_agree(gpu_ctx):
     import torch
     gpu_ctx.load_scene("cornell_box", seed=1)
