@@ -96,6 +96,14 @@ def shade_bytes_per_ray(alive_frac):
     return 56 + 16 + 32 + 32 + 32 + 56.0 * alive_frac + 16.0 * (1.0 - alive_frac)
 
 
+def bounce_bytes_per_ray(primary_frac, alive_frac, nodes_per_ray, prims_per_ray):
+    """k_bounce (fused pipeline): path state in (56 B; a primary ray reads only its 4-B pixel index), 64 B per
+    inner node fetched, 32 B per primitive record tested, the hit primitive (32 B) and its material (32 B)
+    for shading; out: the compacted state of a surviving path (56 B) or the radiance of an ended one (16 B)."""
+    return (56.0 * (1.0 - primary_frac) + 4.0 * primary_frac + 64.0 * nodes_per_ray + 32.0 * prims_per_ray + 64.0 +
+            56.0 * alive_frac + 16.0 * (1.0 - alive_frac))
+
+
 def cpu_baseline(frames_cfg, width, aspect, seconds_target=15.0):
     """The CPU oracle (a port of the reference; the Rust binary cannot be built here) on a bounded
     sample of the same workload: the same frames at full resolution and reduced spp, reference-style
@@ -196,8 +204,9 @@ def main():
         if not args.no_profile:
             trace_ms = sum(st["trace_ms"] for s in stats for st in s)
             shade_ms = sum(st["shade_ms"] for s in stats for st in s)
+            bounce_ms = sum(st["bounce_ms"] for s in stats for st in s)
             # per-ray node fetches / primitive tests of this workload: one instrumented pass at 1 spp (untimed)
-            tr_bytes = sh_bytes = 0.0
+            tr_bytes = sh_bytes = bo_bytes = 0.0
             for f, st_frame in zip(frames, zip(*stats)):
                 f.ctx.profile(events=False, count_visits=True)
                 st = f.render(spp=1)
@@ -207,20 +216,23 @@ def main():
                 f_rays = sum(s["rays"] for s in st_frame)
                 f_paths = sum(s["paths"] for s in st_frame)
                 alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
-                tr_bytes += f_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
-                sh_bytes += f_rays * shade_bytes_per_ray(alive)
+                if st_frame[0]["pipeline"] == 1:
+                    bo_bytes += f_rays * bounce_bytes_per_ray(f_paths / max(f_rays, 1), alive, nodes_pr, prims_pr)
+                else:
+                    tr_bytes += f_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
+                    sh_bytes += f_rays * shade_bytes_per_ray(alive)
             n_tr = sum(st["trace_launches"] for s in stats for st in s)
             n_sh = sum(st["shade_launches"] for s in stats for st in s)
-            if trace_ms >= shade_ms:
-                kernel, ms, nbytes, nl = "k_trace", trace_ms, tr_bytes, n_tr
-            else:
-                kernel, ms, nbytes, nl = "k_shade", shade_ms, sh_bytes, n_sh
+            n_bo = sum(st["bounce_kernel_launches"] for s in stats for st in s)
+            kernel, ms, nbytes, nl = max([("k_trace", trace_ms, tr_bytes, n_tr), ("k_shade", shade_ms, sh_bytes, n_sh),
+                                          ("k_bounce", bounce_ms, bo_bytes, n_bo)], key=lambda k: k[1])
             achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,
                     "launches": int(nl), "avg_launch_ms": round(ms / max(nl, 1), 5),
                     "algorithmic_bytes_per_launch": round(nbytes / max(nl, 1), 1),
-                    "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3)}
+                    "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
+                    "bounce_ms_per_step": round(bounce_ms / args.steps, 3)}
         out = {
             "metric": "Mrays/s (paths x bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -182,12 +182,12 @@ inline M4 m4_inverse(const M4& mm) {
 // RNG.  Specification (the HIP path implements the same spec independently):
 //   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
 //   path stream (seed,pixel,sample): h=mix32(seed^0x51ED270B); k0=mix32(pixel^h);
-//        k1=mix32(k0^mix32(sample+0x68E31DA4));  draw n = mix32(mix32(k0+n)^k1), n=0,1,2,...
+//        k1=mix32(k0^mix32(sample+0x68E31DA4));  draw n = mix32((k0+n)^k1), n=0,1,2,...
 //   f32 in [0,1)   (rand gen::<f32>):        (u32>>8) * 2^-24
 //   f32 in [lo,hi) (rand gen_range):          v=bits(0x3f800000|(u32>>9))-1; r=v*(hi-lo)+lo; redraw if r>=hi
 //   f64 in [0,1)   (rand gen_range(0.0..1.0)): u64=(hi<<32|lo); bits(0x3ff0..|(u64>>12))-1
 //   medium m at bounce b: salt=mix32(m+0x3C6EF372);
-//        word j = mix32(mix32(k0+0x80000000+2b+j)^k1^salt), hi=word0, lo=word1
+//        word j = mix32((k0+0x80000000+2b+j)^k1^salt), hi=word0, lo=word1
 //   index in [0,n): (u32*n)>>32
 // ----------------------------------------------------------------------------
 inline uint32_t mix32(uint32_t x) {
@@ -211,7 +211,7 @@ inline double bits_f64(uint64_t b) {
 struct Stream {
     uint32_t k0, k1, n;
     uint32_t next_u32() {
-        uint32_t r = mix32(mix32(k0 + n) ^ k1);
+        uint32_t r = mix32((k0 + n) ^ k1);
         n++;
         return r;
     }
@@ -235,8 +235,8 @@ inline Stream path_stream(uint32_t seed, uint32_t pixel, uint32_t sample) {
 }
 inline double medium_xi(const Stream& s, uint32_t bounce, uint32_t medium) {
     uint32_t salt = mix32(medium + 0x3C6EF372U);
-    uint32_t hi = mix32(mix32(s.k0 + 0x80000000U + 2 * bounce) ^ s.k1 ^ salt);
-    uint32_t lo = mix32(mix32(s.k0 + 0x80000001U + 2 * bounce) ^ s.k1 ^ salt);
+    uint32_t hi = mix32((s.k0 + 0x80000000U + 2 * bounce) ^ s.k1 ^ salt);
+    uint32_t lo = mix32((s.k0 + 0x80000001U + 2 * bounce) ^ s.k1 ^ salt);
     uint64_t u = ((uint64_t)hi << 32) | lo;
     return bits_f64((u >> 12) | 0x3FF0000000000000ULL) - 1.0;
 }

@@ -612,7 +612,36 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     if ((rc = upload(c, c->d_media, media_groups.data(), media_groups.size() * sizeof(uint32_t)))) return rc;
     static_assert(sizeof(rt_material) == sizeof(rtd::Material), "material layout");
     static_assert(sizeof(rt_texture) == sizeof(rtd::Texture), "texture layout");
-    if ((rc = upload(c, c->d_mats, c->mats.data(), c->mats.size() * sizeof(rt_material)))) return rc;
+    // Device material records: a SolidColor texture is folded into the record (one dependent fetch less per
+    // shade) and "reads (u,v)" is resolved here once, through checker children, instead of per hit.
+    std::vector<rtd::Material> dmats(c->mats.size());
+    for (size_t i = 0; i < c->mats.size(); i++) {
+        const rt_material& m = c->mats[i];
+        rtd::Material& d = dmats[i];
+        d.kind = m.kind;
+        d.tex = m.tex;
+        memcpy(d.albedo, m.albedo, sizeof(d.albedo));
+        d.fuzz = m.fuzz;
+        d.ior = m.ior;
+        d.pad = 0;
+        if (m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC) continue;
+        const rt_texture& t = c->texs[m.tex];
+        if (t.kind == RT_TEX_SOLID) {
+            d.pad |= rtd::MF_SOLID;
+            memcpy(d.albedo, t.color, sizeof(d.albedo));
+        }
+        // walk the checker tree (bounded: a malformed cyclic description must not hang the host)
+        std::vector<uint32_t> todo{m.tex};
+        for (size_t k = 0; k < todo.size() && k < 4096; k++) {
+            const rt_texture& q = c->texs[todo[k]];
+            if (q.kind == RT_TEX_IMAGE) d.pad |= rtd::MF_NEEDS_UV;
+            if (q.kind == RT_TEX_CHECKER) {
+                todo.push_back(q.odd);
+                todo.push_back(q.even);
+            }
+        }
+    }
+    if ((rc = upload(c, c->d_mats, dmats.data(), dmats.size() * sizeof(rtd::Material)))) return rc;
     if ((rc = upload(c, c->d_texs, c->texs.data(), c->texs.size() * sizeof(rt_texture)))) return rc;
     std::vector<rtd::PerlinTable> ptab(n_perlin);
     for (uint32_t t = 0; t < n_perlin; t++) {

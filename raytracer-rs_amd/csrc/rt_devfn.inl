@@ -49,7 +49,7 @@ DEV f3 xf_vector(const float* m, f3 v) {
 // ---- counter-based RNG ------------------------------------------------------
 //   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
 //   stream (seed,pixel,sample): h=mix32(seed^0x51ED270B); k0=mix32(pixel^h);
-//       k1=mix32(k0^mix32(sample+0x68E31DA4)); draw n = mix32(mix32(k0+n)^k1)
+//       k1=mix32(k0^mix32(sample+0x68E31DA4)); draw n = mix32((k0+n)^k1)
 DEV uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352dU;
@@ -61,7 +61,7 @@ DEV uint32_t mix32(uint32_t x) {
 struct Rng {
     uint32_t k0, k1, n;
     DEV uint32_t next() {
-        uint32_t r = mix32(mix32(k0 + n) ^ k1);
+        uint32_t r = mix32((k0 + n) ^ k1);
         n++;
         return r;
     }
@@ -84,8 +84,8 @@ DEV void stream_key(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t& k0
 // f64 uniform of medium `m` at bounce `b`: rand gen_range(0.0..1.0) from a (hi,lo) word pair
 DEV double medium_xi(uint32_t k0, uint32_t k1, uint32_t bounce, uint32_t medium) {
     uint32_t salt = mix32(medium + 0x3C6EF372U);
-    uint32_t hi = mix32(mix32(k0 + 0x80000000U + 2u * bounce) ^ k1 ^ salt);
-    uint32_t lo = mix32(mix32(k0 + 0x80000001U + 2u * bounce) ^ k1 ^ salt);
+    uint32_t hi = mix32((k0 + 0x80000000U + 2u * bounce) ^ k1 ^ salt);
+    uint32_t lo = mix32((k0 + 0x80000001U + 2u * bounce) ^ k1 ^ salt);
     unsigned long long u = ((unsigned long long)hi << 32) | lo;
     return __longlong_as_double((long long)((u >> 12) | 0x3FF0000000000000ULL)) - 1.0;
 }
@@ -448,21 +448,32 @@ DEV uint32_t rust_as_u32(float f) {  // saturating, NaN -> 0
     if (f >= 4294967296.0f) return 0xFFFFFFFFu;
     return (uint32_t)f;
 }
-DEV bool tex_needs_uv(const Scene& S, uint32_t ti) {
-    Texture t = S.texs[ti];
-    return t.kind == TK_IMAGE || t.kind == TK_CHECKER;  // a checker may nest an image
+// Sign of sin(x) without evaluating it: x lies in (k*pi, (k+1)*pi) with k = floor(x/pi) taken in f64 (exact
+// enough for every f32 x), and sin is negative there iff k is odd.  sin(x) is zero only for x == 0.
+DEV bool sin_is_negative(float x) {
+    double k = floor((double)x * 0.31830988618379067153776752674502872);
+    return ((long long)k & 1LL) != 0;
+}
+// `sin(10x)*sin(10y)*sin(10z) < 0` of CheckeredTexture::value (texture.rs:54-56): only the sign of the
+// product is used, so three transcendentals reduce to three parities.  A zero or non-finite factor makes
+// the product zero or NaN, for which `< 0` is false.
+DEV bool checker_is_odd(f3 p) {
+    float x = 10.0f * p.x, y = 10.0f * p.y, z = 10.0f * p.z;
+    bool usable = (x != 0.0f) && (y != 0.0f) && (z != 0.0f) && (__builtin_fabsf(x) < INF_F) && (__builtin_fabsf(y) < INF_F) &&
+                  (__builtin_fabsf(z) < INF_F);
+    bool neg = sin_is_negative(x) ^ sin_is_negative(y) ^ sin_is_negative(z);
+    return usable && neg;
 }
 DEV f3 tex_value(const Scene& S, uint32_t ti, float u, float v, f3 p) {
     const float4* tp = reinterpret_cast<const float4*>(S.texs + ti);
     float4 T0 = tp[0], T1 = tp[1];
-    uint32_t kind = __float_as_uint(T0.x);
+    uint32_t kind = __float_as_uint(T0.x) & 0xFFu;
     for (int it = 0; it < 8 && kind == TK_CHECKER; it++) {  // texture.rs:52-62
-        float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
-        ti = sines < 0.0f ? __float_as_uint(T1.x) : __float_as_uint(T1.y);
+        ti = checker_is_odd(p) ? __float_as_uint(T1.x) : __float_as_uint(T1.y);
         tp = reinterpret_cast<const float4*>(S.texs + ti);
         T0 = tp[0];
         T1 = tp[1];
-        kind = __float_as_uint(T0.x);
+        kind = __float_as_uint(T0.x) & 0xFFu;
     }
     if (kind == TK_NOISE) {  // texture.rs:78-82
         const PerlinTable& P = S.perlin[__float_as_uint(T1.w)];
@@ -500,6 +511,12 @@ DEV float reflectance(float cosine, float ref_index) {  // materials.rs:109-114
     r0 = r0 * r0;
     return r0 + (1.0f - r0) * powf(1.0f - cosine, 5.0f);
 }
+// Texture::value of the material's texture.  The commit step folds SolidColor textures into the material
+// record (MF_SOLID: the colour sits in albedo), which saves a dependent texture fetch.
+DEV f3 material_color(const Scene& S, const Material& M, const Record& rec) {
+    if (M.pad & MF_SOLID) return ld3(M.albedo);
+    return tex_value(S, M.tex, rec.u, rec.v, rec.point);
+}
 // returns true when the path continues; att and the scattered direction are set then
 DEV bool scatter(const Scene& S, const Material& M, f3 wd, const Record& rec, Rng& rng, f3& att, f3& dir) {
     switch (M.kind) {
@@ -508,7 +525,7 @@ DEV bool scatter(const Scene& S, const Material& M, f3 wd, const Record& rec, Rn
             if (__builtin_fabsf(sc.x) < F32_EPSILON && __builtin_fabsf(sc.y) < F32_EPSILON && __builtin_fabsf(sc.z) < F32_EPSILON)
                 sc = rec.normal;
             dir = sc;
-            att = tex_value(S, M.tex, rec.u, rec.v, rec.point);
+            att = material_color(S, M, rec);
             return true;
         }
         case MK_METAL: {  // materials.rs:84-95 (draws even when fuzz == 0)
@@ -532,7 +549,7 @@ DEV bool scatter(const Scene& S, const Material& M, f3 wd, const Record& rec, Rn
         }
         case MK_ISOTROPIC: {  // materials.rs:204-215
             dir = normalize3(rand_in_unit_sphere(rng));
-            att = tex_value(S, M.tex, rec.u, rec.v, rec.point);
+            att = material_color(S, M, rec);
             return true;
         }
         default:  // MK_LIGHT, materials.rs:176-179
@@ -551,13 +568,11 @@ DEV Material load_material(const Scene& S, uint32_t mi) {
     M.albedo[2] = m1.x;
     M.fuzz = m1.y;
     M.ior = m1.z;
-    M.pad = 0;
+    M.pad = __float_as_uint(m1.w);
     return M;
 }
-DEV bool material_needs_uv(const Scene& S, const Material& M) {
-    if (M.kind == MK_METAL || M.kind == MK_DIELECTRIC) return false;
-    return tex_needs_uv(S, M.tex);
-}
+// set at commit: does anything this material evaluates read (u, v)?  (only image textures do)
+DEV bool material_needs_uv(const Material& M) { return (M.pad & MF_NEEDS_UV) != 0; }
 
 DEV uint32_t lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

@@ -65,11 +65,14 @@ struct alignas(16) Group {
 static_assert(sizeof(Group) == 128, "Group must be 128 B");
 
 enum MatKind : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_LIGHT = 3, MK_ISOTROPIC = 4 };
+// flags the commit step writes into Material::pad
+constexpr uint32_t MF_NEEDS_UV = 1u;  // the material's texture (or a checker child of it) is an image
+constexpr uint32_t MF_SOLID = 2u;     // the texture is a SolidColor; its colour has been copied into albedo
 struct alignas(16) Material {
     uint32_t kind, tex;
-    float albedo[3];
+    float albedo[3];  // Metal: albedo; with MF_SOLID: the solid texture's colour
     float fuzz, ior;
-    uint32_t pad;
+    uint32_t pad;     // MF_* flags
 };
 static_assert(sizeof(Material) == 32, "Material must be 32 B");
 

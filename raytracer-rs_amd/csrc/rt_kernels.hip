@@ -90,7 +90,7 @@ DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, con
         mi = __float_as_uint(reinterpret_cast<const float4*>(S.prims + h.prim)[1].y) >> 8;
     const Material M = load_material(S, mi);
     Record rec;
-    if (material_needs_uv(S, M))
+    if (material_needs_uv(M))
         make_record<true>(S, p.o, p.d, p.time, h, rec);
     else
         make_record<false>(S, p.o, p.d, p.time, h, rec);
@@ -109,7 +109,7 @@ DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, con
         return true;
     }
     f3 E{0.0f, 0.0f, 0.0f};  // main.rs:57-59
-    if (M.kind == MK_LIGHT) E = tex_value(S, M.tex, rec.u, rec.v, rec.point);
+    if (M.kind == MK_LIGHT) E = material_color(S, M, rec);
     f3 L = p.T * E;
     radiance[p.slot] = make_float4(L.x, L.y, L.z, 0.0f);
     return false;

@@ -148,7 +148,7 @@ struct Mat4 {
 };
 
 // ---- thread_rng stand-in ----------------------------------------------------------------
-// Counter-based stream (same construction as the render streams): draw n = mix32(mix32(k0+n)^k1).
+// Counter-based stream (same construction as the render streams): draw n = mix32((k0+n)^k1).
 // The scene stream of seed s has k0 = mix32(s^0xA511E9B3), k1 = mix32(s^0x2545F491).
 inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
@@ -165,7 +165,7 @@ class ThreadRng {
         k1_ = mix32(s ^ 0x2545F491U);
         n_ = 0;
     }
-    uint32_t next_u32() { return mix32(mix32(k0_ + n_++) ^ k1_); }
+    uint32_t next_u32() { return mix32((k0_ + n_++) ^ k1_); }
     float gen() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }  // rng.gen::<f32>()
     float gen_range(float lo, float hi) {                                      // rng.gen_range(lo..hi)
         float scale = hi - lo;

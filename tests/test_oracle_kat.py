@@ -312,7 +312,7 @@ def stream_key(seed, pixel, sample):
 def test_rng_matches_specification():
     seed, pixel, sample = 12345, 777, 42
     k0, k1 = stream_key(seed, pixel, sample)
-    want = [mix32(mix32((k0 + n) & M32) ^ k1) for n in range(16)]
+    want = [mix32(((k0 + n) & M32) ^ k1) for n in range(16)]
     got = np.empty(16, np.uint32)
     orc.lib().orc_rng_u32(seed, pixel, sample, 16, got.ctypes.data)
     assert got.tolist() == want
@@ -324,8 +324,8 @@ def test_rng_matches_specification():
     exp = [np.float32((np.array([0x3F800000 | (x >> 9)], np.uint32).view(np.float32)[0] - np.float32(1.0)) * np.float32(2.0) + np.float32(-1.0)) for x in want]
     assert r.tolist() == exp
     salt = mix32(3 + 0x3C6EF372)
-    hi = mix32(mix32((k0 + 0x80000000 + 2 * 5) & M32) ^ k1 ^ salt)
-    lo = mix32(mix32((k0 + 0x80000001 + 2 * 5) & M32) ^ k1 ^ salt)
+    hi = mix32(((k0 + 0x80000000 + 2 * 5) & M32) ^ k1 ^ salt)
+    lo = mix32(((k0 + 0x80000001 + 2 * 5) & M32) ^ k1 ^ salt)
     xi = np.array([(((hi << 32) | lo) >> 12) | 0x3FF0000000000000], np.uint64).view(np.float64)[0] - 1.0
     assert orc.lib().orc_rng_medium_xi(seed, pixel, sample, 5, 3) == xi
 
