@@ -161,7 +161,7 @@ int rt_intersect_batch(rt_ctx* ctx, uint64_t n, const float* ox, const float* oy
 typedef struct rt_render_params {
     uint32_t width, height;
     uint32_t sample0, sample1;
-    uint32_t max_depth; /* 50 in every reference preset */
+    uint32_t max_depth; /* 1..253; 50 in every reference preset */
     float background[3];
     uint32_t seed;
     uint32_t tile_size; /* 0 -> 32 */

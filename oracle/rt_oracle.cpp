@@ -182,7 +182,12 @@ inline M4 m4_inverse(const M4& mm) {
 // RNG.  Specification (the HIP path implements the same spec independently):
 //   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
 //   path stream (seed,pixel,sample): h=mix32(seed^0x51ED270B); k0=mix32(pixel^h);
-//        k1=mix32(k0^mix32(sample+0x68E31DA4));  draw n = mix32((k0+n)^k1), n=0,1,2,...
+//        k1=mix32(k0^mix32(sample+0x68E31DA4));  draw at counter c = mix32((k0+c)^k1)
+//   counters of one path: every consumer starts at a fixed counter and counts up from there, so no
+//   consumer's draws depend on how many draws another one's rejection loop took:
+//        pixel jitter s, t, then the ray time     c = 0xFF000000, 0xFF000001, 0xFF000002...
+//        lens disk (random_in_unit_disk)           c = 0xFE000000...
+//        Material::scatter at bounce b (b < 254)   c = b<<24 ...
 //   f32 in [0,1)   (rand gen::<f32>):        (u32>>8) * 2^-24
 //   f32 in [lo,hi) (rand gen_range):          v=bits(0x3f800000|(u32>>9))-1; r=v*(hi-lo)+lo; redraw if r>=hi
 //   f64 in [0,1)   (rand gen_range(0.0..1.0)): u64=(hi<<32|lo); bits(0x3ff0..|(u64>>12))-1
@@ -227,6 +232,7 @@ struct Stream {
     }
     uint32_t gen_index(uint32_t n_) { return (uint32_t)(((uint64_t)next_u32() * n_) >> 32); }
 };
+constexpr uint32_t CTR_CAMERA = 0xFF000000U, CTR_LENS = 0xFE000000U;
 inline Stream path_stream(uint32_t seed, uint32_t pixel, uint32_t sample) {
     uint32_t h = mix32(seed ^ 0x51ED270BU);
     uint32_t k0 = mix32(pixel ^ h);
@@ -949,7 +955,8 @@ struct Camera {
         return c;
     }
     Ray get_ray(float s, float t, Stream& rng) const {
-        V3 rd = lens_radius * random_in_unit_disk(rng);
+        Stream lens{rng.k0, rng.k1, CTR_LENS};
+        V3 rd = lens_radius * random_in_unit_disk(lens);
         V3 offset = u * rd.x + v * rd.y;
         Ray r;
         r.origin = origin + offset;
@@ -959,6 +966,7 @@ struct Camera {
     }
 };
 inline Ray camera_sample_ray(const Camera& cam, int w, int h, int i, int j, Stream& rng) {  // src/main.rs:471-474
+    rng.n = CTR_CAMERA;
     float u = ((float)i + rng.gen_f32()) / (float)(w - 1);
     float v = ((float)(h - 1 - j) + rng.gen_f32()) / (float)(h - 1);
     return cam.get_ray(u, v, rng);
@@ -989,6 +997,7 @@ struct World {
 V3 ray_color(const Ray& ray, V3 background, const World& world, int depth, int max_depth) {
     if (depth <= 0) return {0, 0, 0};
     g_path->bounce = (uint32_t)(max_depth - depth);
+    g_path->rng.n = g_path->bounce << 24;
     g_cnt_rays++;
     HitRecord rec;
     if (world.intersect(ray, 0.005f, INF, rec)) {
@@ -1423,6 +1432,7 @@ int orc_gen_rays(const orc_scene* S, int w, int h, float aspect, uint32_t seed, 
         if (which == 1) {
             HitRecord rec;
             ok = 0;
+            ctx.rng.n = 0;  // scatter counters of bounce 0
             if (world.intersect(r, 0.005f, INF, rec)) {
                 Ray sc{{0, 0, 0}, {0, 0, 0}, r.time};
                 V3 att{1, 1, 1};
@@ -1504,16 +1514,19 @@ void orc_resolve_u8(const float* sum_rgb, int64_t n_pixels, int spp, uint8_t* ou
     for (int64_t i = 0; i < n_pixels * 3; i++) out[i] = float_to_u8_color(sum_rgb[i] * inv);
 }
 
-void orc_rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out) {
+void orc_rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first, int n, uint32_t* out) {
     Stream s = path_stream(seed, pixel, sample);
+    s.n = first;
     for (int i = 0; i < n; i++) out[i] = s.next_u32();
 }
-void orc_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, int n, float* out) {
+void orc_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first, int n, float* out) {
     Stream s = path_stream(seed, pixel, sample);
+    s.n = first;
     for (int i = 0; i < n; i++) out[i] = s.gen_f32();
 }
-void orc_rng_range(uint32_t seed, uint32_t pixel, uint32_t sample, float lo, float hi, int n, float* out) {
+void orc_rng_range(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first, float lo, float hi, int n, float* out) {
     Stream s = path_stream(seed, pixel, sample);
+    s.n = first;
     for (int i = 0; i < n; i++) out[i] = s.gen_range(lo, hi);
 }
 double orc_rng_medium_xi(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t medium) {

@@ -88,9 +88,9 @@ int orc_render(const orc_scene*, int mode, int w, int h, float aspect,
 void orc_resolve_u8(const float* sum_rgb, int64_t n_pixels, int spp, uint8_t* out);
 
 // ---- RNG specification probes ---------------------------------------------
-void orc_rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out);
-void orc_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, int n, float* out);
-void orc_rng_range(uint32_t seed, uint32_t pixel, uint32_t sample, float lo, float hi, int n, float* out);
+void orc_rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first, int n, uint32_t* out);
+void orc_rng_f32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first, int n, float* out);
+void orc_rng_range(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first, float lo, float hi, int n, float* out);
 double orc_rng_medium_xi(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t medium);
 
 // ---- known-answer probes on single objects ---------------------------------

@@ -809,7 +809,11 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (p->width < 2 || p->height < 2 || (uint64_t)p->width * p->height > (1ull << 31))
         return fail(c, RT_ERR_INVALID, "rt_render: image size out of range");
     if (p->sample1 < p->sample0) return fail(c, RT_ERR_INVALID, "rt_render: sample1 < sample0");
-    if (p->max_depth == 0 || p->max_depth > 255) return fail(c, RT_ERR_INVALID, "rt_render: max_depth must be 1..255");
+    if (p->max_depth == 0 || p->max_depth > 253) return fail(c, RT_ERR_INVALID, "rt_render: max_depth must be 1..253");
+    // camera.rs:63 draws the ray time with gen_range(time_start..time_end), which panics on an empty range
+    if (!(cam->time_start < cam->time_end) || !std::isfinite(cam->time_end - cam->time_start))
+        return fail(c, RT_ERR_INVALID, "rt_render: camera needs finite time_start < time_end");
+    if (!std::isfinite(cam->lens_radius)) return fail(c, RT_ERR_INVALID, "rt_render: camera lens_radius is not finite");
     const uint32_t ts = p->tile_size ? p->tile_size : 32, nranks = p->nranks ? p->nranks : 1;
     if (p->rank >= nranks) return fail(c, RT_ERR_INVALID, "rt_render: rank >= nranks");
     HIP_TRY(c, hipSetDevice(c->device));

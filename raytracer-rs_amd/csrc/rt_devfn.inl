@@ -49,7 +49,11 @@ DEV f3 xf_vector(const float* m, f3 v) {
 // ---- counter-based RNG ------------------------------------------------------
 //   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
 //   stream (seed,pixel,sample): h=mix32(seed^0x51ED270B); k0=mix32(pixel^h);
-//       k1=mix32(k0^mix32(sample+0x68E31DA4)); draw n = mix32((k0+n)^k1)
+//       k1=mix32(k0^mix32(sample+0x68E31DA4)); draw at counter c = mix32((k0+c)^k1)
+//   Each consumer of a path's stream counts up from its own fixed counter, so the length of one rejection
+//   loop never shifts the draws of another: jitter + ray time from CTR_CAMERA, the lens disk from CTR_LENS,
+//   the scatter draws of bounce b from b<<24.
+constexpr uint32_t CTR_CAMERA = 0xFF000000U, CTR_LENS = 0xFE000000U;
 DEV uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352dU;
@@ -75,6 +79,8 @@ struct Rng {
             if (r < hi) return r;
         }
     }
+    // range(-1, 1): (v12 - 1) * 2 - 1 is exact and at most 1 - 2^-22, so the redraw can never fire
+    DEV float range_pm1() { return __uint_as_float(0x40000000U | (next() >> 9)) - 3.0f; }
 };
 DEV void stream_key(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t& k0, uint32_t& k1) {
     uint32_t h = mix32(seed ^ 0x51ED270BU);
@@ -94,9 +100,11 @@ DEV f3 rand_range3(Rng& r, float lo, float hi) {
     return {x, y, z};
 }
 DEV f3 rand_in_unit_sphere(Rng& r) {  // vec3_helpers.rs:25-31
-    f3 p = rand_range3(r, -1.0f, 1.0f);
-    while (dot3(p, p) >= 1.0f) p = rand_range3(r, -1.0f, 1.0f);
-    return p;
+    for (;;) {
+        float x = r.range_pm1(), y = r.range_pm1(), z = r.range_pm1();
+        f3 p{x, y, z};
+        if (!(dot3(p, p) >= 1.0f)) return p;
+    }
 }
 
 // ---- primitives ---------------------------------------------------------------

@@ -18,7 +18,7 @@ constexpr int MAX_BLOCKS_PER_SHARD = 32;  // 2048 blocks = 8 per CU; larger queu
 struct PathState {
     float4* o_time;    // origin.xyz, time
     float4* d_slot;    // direction.xyz, bits(slot)
-    float4* thr_meta;  // throughput.xyz, bits(bounce << 24 | rng counter)
+    float4* thr_meta;  // throughput.xyz, spare word
     uint2* key;        // RNG stream key (k0, k1)
 };
 

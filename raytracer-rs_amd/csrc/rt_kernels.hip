@@ -21,7 +21,7 @@ namespace {
 struct PathRegs {
     f3 o, d, T;
     float time;
-    uint32_t k0, k1, meta, slot;  // meta = bounce << 24 | rng counter
+    uint32_t k0, k1, slot;  // every path of one launch is at the same bounce, so the bounce is not stored
 };
 
 // Jitter + Camera::get_ray for path slot `slot` of the batch (main.rs:471-474, camera.rs:54-65).
@@ -33,25 +33,30 @@ DEV void camera_path(const rtk::RenderConst& rc, const rtk::Batch& b, uint32_t s
     uint32_t i = pixel % rc.width, j = pixel / rc.width;
     Rng rng;
     stream_key(rc.seed, pixel, sample, rng.k0, rng.k1);
-    rng.n = 0;
+    rng.n = CTR_CAMERA;
     float u = ((float)i + rng.f32()) / (float)(rc.width - 1);
     float v = ((float)(rc.height - 1 - j) + rng.f32()) / (float)(rc.height - 1);
-    // vec3_helpers.rs:47-60: the first point with |p|^2 >= 1 (sic), drawn even when the aperture is 0
-    float px, py;
-    for (;;) {
-        px = rng.range(-1.0f, 1.0f);
-        py = rng.range(-1.0f, 1.0f);
-        if ((px * px + py * py) + 0.0f * 0.0f >= 1.0f) break;
+    // vec3_helpers.rs:47-60: the first point with |p|^2 >= 1 (sic).  The reference draws it even when the
+    // aperture is 0 and then scales it by 0; the lens draws have their own counters, so skipping them there
+    // changes nothing else.
+    f3 offset{0.0f, 0.0f, 0.0f};
+    if (rc.cam.lens_radius != 0.0f) {
+        Rng lens{rng.k0, rng.k1, CTR_LENS};
+        float px, py;
+        for (;;) {
+            px = lens.range_pm1();
+            py = lens.range_pm1();
+            if ((px * px + py * py) + 0.0f * 0.0f >= 1.0f) break;
+        }
+        float rdx = rc.cam.lens_radius * px, rdy = rc.cam.lens_radius * py;
+        offset = ld3(rc.cam.u) * rdx + ld3(rc.cam.v) * rdy;
     }
-    float rdx = rc.cam.lens_radius * px, rdy = rc.cam.lens_radius * py;
-    f3 offset = ld3(rc.cam.u) * rdx + ld3(rc.cam.v) * rdy;
     p.o = ld3(rc.cam.origin) + offset;
     p.d = ld3(rc.cam.llc) + u * ld3(rc.cam.horizontal) + v * ld3(rc.cam.vertical) - ld3(rc.cam.origin) - offset;
     p.time = rng.range(rc.cam.time_start, rc.cam.time_end);
     p.T = {1.0f, 1.0f, 1.0f};
     p.k0 = rng.k0;
     p.k1 = rng.k1;
-    p.meta = rng.n & 0x00FFFFFFu;
     p.slot = slot;
 }
 
@@ -63,20 +68,20 @@ DEV void load_path(const rtk::PathState& st, uint32_t idx, PathRegs& p) {
     p.d = {ds.x, ds.y, ds.z};
     p.slot = __float_as_uint(ds.w);
     p.T = {tm.x, tm.y, tm.z};
-    p.meta = __float_as_uint(tm.w);
     p.k0 = key.x;
     p.k1 = key.y;
 }
 DEV void store_path(const rtk::PathState& st, uint32_t idx, const PathRegs& p) {
     st.o_time[idx] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
     st.d_slot[idx] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(p.slot));
-    st.thr_meta[idx] = make_float4(p.T.x, p.T.y, p.T.z, __uint_as_float(p.meta));
+    st.thr_meta[idx] = make_float4(p.T.x, p.T.y, p.T.z, 0.0f);
     st.key[idx] = make_uint2(p.k0, p.k1);
 }
 
 // One step of ray_color (main.rs:44-63) after the hit is known.  Returns true when the path goes on (p is
 // then the scattered ray with the updated throughput); otherwise its radiance has been written.
-DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, const Hit& h, float4* __restrict__ radiance) {
+DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, const Hit& h, uint32_t bounce,
+                    float4* __restrict__ radiance) {
     if (h.prim == HIT_NONE) {  // main.rs:60-62
         f3 L = p.T * ld3(rc.background);
         radiance[p.slot] = make_float4(L.x, L.y, L.z, 0.0f);
@@ -94,8 +99,7 @@ DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, con
         make_record<true>(S, p.o, p.d, p.time, h, rec);
     else
         make_record<false>(S, p.o, p.d, p.time, h, rec);
-    const uint32_t bounce = p.meta >> 24;
-    Rng rng{p.k0, p.k1, p.meta & 0x00FFFFFFu};
+    Rng rng{p.k0, p.k1, bounce << 24};
     f3 att{1.0f, 1.0f, 1.0f}, dir{0.0f, 0.0f, 0.0f};
     if (scatter(S, M, p.d, rec, rng, att, dir)) {
         if (bounce + 1u >= rc.max_depth) {  // main.rs:45-47: the next ray_color call returns zero
@@ -105,7 +109,6 @@ DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, con
         p.T = p.T * att;
         p.o = rec.point;
         p.d = dir;
-        p.meta = ((bounce + 1u) << 24) | (rng.n & 0x00FFFFFFu);
         return true;
     }
     f3 E{0.0f, 0.0f, 0.0f};  // main.rs:57-59
@@ -184,9 +187,9 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_bounce(Scene S, rtk::RenderConst
             else
                 load_path(in, shard_base + i, p);
             Hit h;
-            trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, p.meta >> 24, h, stk,
+            trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk,
                                                         overflow_flag, &tc);
-            alive = shade_path(S, rc, p, h, radiance);
+            alive = shade_path(S, rc, p, h, bounce, radiance);
         }
         compact_store(clds, parity, alive, p, out, out_count, shard_base);
     }
@@ -232,16 +235,15 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
         const uint32_t idx = shard_base + i;
         float4 ot = in.o_time[idx];
         float4 ds = in.d_slot[idx];
-        uint32_t k0 = 0, k1 = 0, b = 0;
+        uint32_t k0 = 0, k1 = 0;
         if (GROUPS) {
             uint2 key = in.key[idx];
             k0 = key.x;
             k1 = key.y;
-            b = __float_as_uint(in.thr_meta[idx].w) >> 24;
         }
         Hit h;
         trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, k0,
-                                                    k1, b, h, stk, overflow_flag, &tc);
+                                                    k1, bounce, h, stk, overflow_flag, &tc);
         hits[idx] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), 0.0f);
     }
     if (COUNT) {
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_shade(Scene S, rtk::RenderConst 
             h.prim = __float_as_uint(hv.y);
             h.grp = __float_as_int(hv.z);
             h.key = 0;
-            alive = shade_path(S, rc, p, h, radiance);
+            alive = shade_path(S, rc, p, h, bounce, radiance);
         }
         compact_store(clds, parity, alive, p, out, out_count, shard_base);
     }

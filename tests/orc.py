@@ -46,9 +46,9 @@ def lib():
     L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_uint32,
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_resolve_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
-    L.orc_rng_u32.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
-    L.orc_rng_f32.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
-    L.orc_rng_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, c_f, c_f, C.c_int, C.c_void_p]
+    L.orc_rng_u32.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    L.orc_rng_f32.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    L.orc_rng_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, c_f, c_f, C.c_int, C.c_void_p]
     L.orc_rng_medium_xi.restype = C.c_double
     L.orc_rng_medium_xi.argtypes = [C.c_uint32] * 5
     L.orc_kat_sphere.argtypes = [c_fp, c_f, c_fp, c_f, c_f, c_fp]

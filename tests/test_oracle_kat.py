@@ -280,12 +280,32 @@ def test_camera_new_and_get_ray():
     w, h = 5, 3
     orc.lib().orc_kat_camera_ray(cam.ctypes.data_as(C.POINTER(C.c_float)), w, h, 2, 1, 1, 0, r)
     jit = np.empty(2, np.float32)
-    orc.lib().orc_rng_f32(1, 1 * w + 2, 0, 2, jit.ctypes.data)
+    orc.lib().orc_rng_f32(1, 1 * w + 2, 0, 0xFF000000, 2, jit.ctypes.data)  # jitter counters
     u = (2 + jit[0]) / (w - 1)
     v = ((h - 1 - 1) + jit[1]) / (h - 1)
     assert list(r[0:3]) == [0.0, 0.0, 0.0]  # lens radius 0 (the disk sampler still runs, camera.rs:55)
     assert r[3] == pytest.approx(-2 + 4 * u, abs=1e-6) and r[4] == pytest.approx(-1 + 2 * v, abs=1e-6) and r[5] == -1.0
-    assert 0.0 <= r[6] < 1.0
+    tm = np.empty(1, np.float32)
+    orc.lib().orc_rng_range(1, 1 * w + 2, 0, 0xFF000002, 0.0, 1.0, 1, tm.ctypes.data)  # time follows the jitter
+    assert r[6] == tm[0] and 0.0 <= r[6] < 1.0
+
+
+def test_camera_lens_draws_have_their_own_counters():
+    # aperture 0.5 -> lens radius 0.25; u=(1,0,0), v=(0,1,0).  The lens point is the first pair from counter
+    # 0xFE000000 on with x^2+y^2 >= 1 (vec3_helpers.rs:47-60, sic); jitter and time do not move with it.
+    cam = orc.camera_new((0, 0, 0), (0, 0, -1), (0, 1, 0), math.radians(90), 2.0, 0.5, 1.0, 0.0, 1.0)
+    w, h = 5, 3
+    for px in range(w * h):
+        i, j = px % w, px // w
+        r = (C.c_float * 7)()
+        orc.lib().orc_kat_camera_ray(cam.ctypes.data_as(C.POINTER(C.c_float)), w, h, i, j, 7, 3, r)
+        d = np.empty(64, np.float32)
+        orc.lib().orc_rng_range(7, px, 3, 0xFE000000, -1.0, 1.0, 64, d.ctypes.data)
+        k = next(k for k in range(32) if np.float32(d[2 * k] * d[2 * k]) + np.float32(d[2 * k + 1] * d[2 * k + 1]) >= 1.0)
+        assert r[0] == np.float32(0.25) * d[2 * k] and r[1] == np.float32(0.25) * d[2 * k + 1] and r[2] == 0.0
+        tm = np.empty(1, np.float32)
+        orc.lib().orc_rng_range(7, px, 3, 0xFF000002, 0.0, 1.0, 1, tm.ctypes.data)
+        assert r[6] == tm[0]
 
 
 # ---- the RNG specification, restated in Python ---------------------------------------------------------
@@ -314,13 +334,16 @@ def test_rng_matches_specification():
     k0, k1 = stream_key(seed, pixel, sample)
     want = [mix32(((k0 + n) & M32) ^ k1) for n in range(16)]
     got = np.empty(16, np.uint32)
-    orc.lib().orc_rng_u32(seed, pixel, sample, 16, got.ctypes.data)
+    orc.lib().orc_rng_u32(seed, pixel, sample, 0, 16, got.ctypes.data)
     assert got.tolist() == want
+    first = 0xFE000000  # any starting counter, wrapping included
+    orc.lib().orc_rng_u32(seed, pixel, sample, first, 16, got.ctypes.data)
+    assert got.tolist() == [mix32(((k0 + first + n) & M32) ^ k1) for n in range(16)]
     f = np.empty(16, np.float32)
-    orc.lib().orc_rng_f32(seed, pixel, sample, 16, f.ctypes.data)
+    orc.lib().orc_rng_f32(seed, pixel, sample, 0, 16, f.ctypes.data)
     assert f.tolist() == [np.float32(x >> 8) * np.float32(2.0 ** -24) for x in want]
     r = np.empty(16, np.float32)
-    orc.lib().orc_rng_range(seed, pixel, sample, -1.0, 1.0, 16, r.ctypes.data)
+    orc.lib().orc_rng_range(seed, pixel, sample, 0, -1.0, 1.0, 16, r.ctypes.data)
     exp = [np.float32((np.array([0x3F800000 | (x >> 9)], np.uint32).view(np.float32)[0] - np.float32(1.0)) * np.float32(2.0) + np.float32(-1.0)) for x in want]
     assert r.tolist() == exp
     salt = mix32(3 + 0x3C6EF372)
@@ -333,11 +356,11 @@ def test_rng_matches_specification():
 def test_rng_is_uniform_enough():
     n = 1 << 16
     f = np.empty(n, np.float32)
-    orc.lib().orc_rng_f32(1, 0, 0, n, f.ctypes.data)
+    orc.lib().orc_rng_f32(1, 0, 0, 0, n, f.ctypes.data)
     assert abs(f.mean() - 0.5) < 0.005 and abs(f.var() - 1 / 12) < 0.002 and 0.0 <= f.min() and f.max() < 1.0
     # different pixels / samples give unrelated streams
     g = np.empty(n, np.float32)
-    orc.lib().orc_rng_f32(1, 1, 0, n, g.ctypes.data)
+    orc.lib().orc_rng_f32(1, 1, 0, 0, n, g.ctypes.data)
     assert abs(np.corrcoef(f, g)[0, 1]) < 0.02
 
 
