@@ -80,7 +80,7 @@ struct rt_ctx {
     uint64_t capacity = 0;
     uint32_t cap_shard = 0;
     int pipeline = -1;  // -1 choose per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce)
-    uint64_t fused_node_limit = 64;  // scenes with at most this many BVH nodes take the fused pipeline
+    uint64_t fused_node_limit = 4096;  // scenes with at most this many BVH nodes take the fused pipeline
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
     uint64_t n_owned = 0;
@@ -253,7 +253,7 @@ int alloc_wavefront(rt_ctx* c, uint64_t cap, bool need_hits) {
         }
         if ((rc = ensure(c, c->d_radiance, cap * sizeof(float4)))) return rc;
         if ((rc = ensure(c, c->d_counts, 3 * rtk::NSHARD * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(c, c->d_rays, 32))) return rc;
+        if ((rc = ensure(c, c->d_rays, 128))) return rc;
         if ((rc = ensure(c, c->d_overflow, 16))) return rc;
         c->capacity = cap;
         c->cap_shard = (uint32_t)cap_shard;
@@ -318,13 +318,13 @@ int rt_ctx_create(int device, rt_ctx** out) {
     }
     c->stream = c->own_stream;
     if (hipHostMalloc((void**)&c->h_counts, (rtk::NSHARD + 16) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_rays, 64, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_rays, 128, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return RT_ERR_HIP;
     }
     c->max_paths = (uint64_t)env_u32("RTAMD_MAX_PATHS_MI", 64) << 20;
     if (getenv("RTAMD_PIPELINE")) c->pipeline = (int)env_u32("RTAMD_PIPELINE", 1) ? 1 : 0;  // 0 split, 1 fused
-    c->fused_node_limit = env_u32("RTAMD_FUSED_NODE_LIMIT", 64);
+    c->fused_node_limit = env_u32("RTAMD_FUSED_NODE_LIMIT", 4096);
     *out = c;
     return RT_OK;
 }
@@ -862,7 +862,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (n_owned && n_samples_total) {
         const uint64_t cap = std::min<uint64_t>(c->max_paths, n_owned * (uint64_t)n_samples_total);
         if ((rc = alloc_wavefront(c, std::max<uint64_t>(cap, 1024), !fused))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 24, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 128, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
         const rtk::Queues q{(uint32_t*)c->d_counts.p, c->cap_shard};
         const rtk::TraceCfg tcfg{c->stack_entries, c->has_groups, c->count_visits};
@@ -921,7 +921,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 }
             }
         }
-        HIP_TRY(c, hipMemcpyAsync(c->h_rays, c->d_rays.p, 24, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_rays, c->d_rays.p, 128, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts + rtk::NSHARD, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
     }
     if (!accum_dev) HIP_TRY(c, hipMemcpyAsync(accum_rgb, d_accum, accum_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -930,6 +930,14 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         st.rays = c->h_rays[0];
         st.node_visits = c->h_rays[1];
         st.prim_tests = c->h_rays[2];
+        if (c->count_visits && getenv("RTAMD_SECTION_CYCLES")) {
+            // instrumented fused kernel: wave cycles per section, summed over waves (words 3..6), wave tiles (7)
+            const unsigned long long* h = c->h_rays;
+            double tot = (double)(h[3] + h[4] + h[5] + h[6]);
+            if (tot > 0)
+                fprintf(stderr, "[rtamd] wave cycles per tile: fetch/raygen %.0f  trace %.0f  shade %.0f  compact %.0f  (tiles %llu)\n",
+                        h[3] / (double)h[7], h[4] / (double)h[7], h[5] / (double)h[7], h[6] / (double)h[7], h[7]);
+        }
         if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     }
     if (c->profile) {

@@ -412,42 +412,60 @@ DEV void make_record(const Scene& S, f3 wo, f3 wd, float time, const Hit& h, Rec
 }
 
 // ---- textures (texture.rs, perlin.rs) -------------------------------------------
+// The noise value only feeds a colour (no hit decision hangs on it), so it is evaluated in the cheapest
+// accurate form rather than in the reference's operation order: the eight-corner weighted sum of
+// perlin.rs:71-85 is the trilinear interpolation of the corner dot products with the Hermite weights, here
+// written as seven fused lerps.  Agreement with the reference order is at the 1e-7 level.
+DEV float perlin_corner(const PerlinTable& P, int h, float du, float dv, float dw) {
+    const float4 g = *reinterpret_cast<const float4*>(P.vec[h & 255]);
+    return __builtin_fmaf(g.z, dw, __builtin_fmaf(g.y, dv, g.x * du));
+}
 DEV float perlin_noise(const PerlinTable& P, f3 p) {  // perlin.rs:46-88
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
-    float uu = u * u * (3.0f - 2.0f * u);
-    float vv = v * v * (3.0f - 2.0f * v);
-    float ww = w * w * (3.0f - 2.0f * w);
-    float acc = 0.0f;
-#pragma unroll
-    for (int di = 0; di < 2; di++)
-#pragma unroll
-        for (int dj = 0; dj < 2; dj++)
-#pragma unroll
-            for (int dk = 0; dk < 2; dk++) {
-                int idx = P.perm[0][(uint32_t)(i + di) & 255u] ^ P.perm[1][(uint32_t)(j + dj) & 255u] ^
-                          P.perm[2][(uint32_t)(k + dk) & 255u];
-                const float4 c4 = *reinterpret_cast<const float4*>(P.vec[idx & 255]);
-                f3 c{c4.x, c4.y, c4.z};
-                f3 weight{u - (float)di, v - (float)dj, w - (float)dk};
-                float wu = di ? uu : (1.0f - uu);
-                float wv = dj ? vv : (1.0f - vv);
-                float wwv = dk ? ww : (1.0f - ww);
-                acc += wu * wv * wwv * dot3(weight, c);
-            }
-    return acc;
+    float uu = u * u * __builtin_fmaf(-2.0f, u, 3.0f);
+    float vv = v * v * __builtin_fmaf(-2.0f, v, 3.0f);
+    float ww = w * w * __builtin_fmaf(-2.0f, w, 3.0f);
+    const int x0 = P.perm[0][(uint32_t)i & 255u], x1 = P.perm[0][(uint32_t)(i + 1) & 255u];
+    const int y0 = P.perm[1][(uint32_t)j & 255u], y1 = P.perm[1][(uint32_t)(j + 1) & 255u];
+    const int z0 = P.perm[2][(uint32_t)k & 255u], z1 = P.perm[2][(uint32_t)(k + 1) & 255u];
+    const float u1 = u - 1.0f, v1 = v - 1.0f, w1 = w - 1.0f;
+    const int h00 = x0 ^ y0, h01 = x0 ^ y1, h10 = x1 ^ y0, h11 = x1 ^ y1;
+    float a, b;
+    a = perlin_corner(P, h00 ^ z0, u, v, w);
+    b = perlin_corner(P, h00 ^ z1, u, v, w1);
+    const float c00 = __builtin_fmaf(ww, b - a, a);
+    a = perlin_corner(P, h01 ^ z0, u, v1, w);
+    b = perlin_corner(P, h01 ^ z1, u, v1, w1);
+    const float c01 = __builtin_fmaf(ww, b - a, a);
+    a = perlin_corner(P, h10 ^ z0, u1, v, w);
+    b = perlin_corner(P, h10 ^ z1, u1, v, w1);
+    const float c10 = __builtin_fmaf(ww, b - a, a);
+    a = perlin_corner(P, h11 ^ z0, u1, v1, w);
+    b = perlin_corner(P, h11 ^ z1, u1, v1, w1);
+    const float c11 = __builtin_fmaf(ww, b - a, a);
+    const float c0 = __builtin_fmaf(vv, c01 - c00, c00);
+    const float c1 = __builtin_fmaf(vv, c11 - c10, c10);
+    return __builtin_fmaf(uu, c1 - c0, c0);
 }
 DEV float perlin_turb(const PerlinTable& P, f3 p, int depth) {  // perlin.rs:90-102
     float acc = 0.0f;
     f3 temp = p;
     float weight = 1.0f;
     for (int i = 0; i < depth; i++) {
-        acc += weight * perlin_noise(P, temp);
+        acc = __builtin_fmaf(weight, perlin_noise(P, temp), acc);
         weight *= 0.5f;
         temp = 2.0f * temp;
     }
     return __builtin_fabsf(acc);
+}
+// sin(x) to ~1e-6 absolute for any finite f32 x: the turn count x/2pi is reduced in f64 (exact to 1e-16 of a
+// turn), the hardware sine takes the remaining fraction of a turn.  Used for colours only.
+DEV float sin_turns(float x) {
+    double t = (double)x * 0.15915494309189533577;
+    t -= __builtin_rint(t);
+    return __builtin_amdgcn_sinf((float)t);
 }
 DEV float rust_clamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 DEV uint32_t rust_as_u32(float f) {  // saturating, NaN -> 0
@@ -457,18 +475,20 @@ DEV uint32_t rust_as_u32(float f) {  // saturating, NaN -> 0
     return (uint32_t)f;
 }
 // Sign of sin(x) without evaluating it: x lies in (k*pi, (k+1)*pi) with k = floor(x/pi) taken in f64 (exact
-// enough for every f32 x), and sin is negative there iff k is odd.  sin(x) is zero only for x == 0.
+// enough for every f32 x), and sin is negative there iff k is odd, i.e. iff frac(x/2pi) >= 1/2 (the halving
+// is exact).  sin(x) is zero only for x == 0.
 DEV bool sin_is_negative(float x) {
-    double k = floor((double)x * 0.31830988618379067153776752674502872);
-    return ((long long)k & 1LL) != 0;
+    double h = (double)x * (0.5 * 0.31830988618379067153776752674502872);
+    return __builtin_amdgcn_fract(h) >= 0.5;
 }
 // `sin(10x)*sin(10y)*sin(10z) < 0` of CheckeredTexture::value (texture.rs:54-56): only the sign of the
 // product is used, so three transcendentals reduce to three parities.  A zero or non-finite factor makes
 // the product zero or NaN, for which `< 0` is false.
 DEV bool checker_is_odd(f3 p) {
     float x = 10.0f * p.x, y = 10.0f * p.y, z = 10.0f * p.z;
-    bool usable = (x != 0.0f) && (y != 0.0f) && (z != 0.0f) && (__builtin_fabsf(x) < INF_F) && (__builtin_fabsf(y) < INF_F) &&
-                  (__builtin_fabsf(z) < INF_F);
+    float lo = fminf(fminf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
+    float hi = fmaxf(fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)), __builtin_fabsf(z));
+    bool usable = lo > 0.0f && hi < INF_F;  // false as well when any factor is NaN
     bool neg = sin_is_negative(x) ^ sin_is_negative(y) ^ sin_is_negative(z);
     return usable && neg;
 }
@@ -485,7 +505,7 @@ DEV f3 tex_value(const Scene& S, uint32_t ti, float u, float v, f3 p) {
     }
     if (kind == TK_NOISE) {  // texture.rs:78-82
         const PerlinTable& P = S.perlin[__float_as_uint(T1.w)];
-        float s = 1.0f + sinf(T1.z * p.z + 10.0f * perlin_turb(P, p, 7));
+        float s = 1.0f + sin_turns(__builtin_fmaf(10.0f, perlin_turb(P, p, 7), T1.z * p.z));
         return {0.5f * s, 0.5f * s, 0.5f * s};
     }
     if (kind == TK_IMAGE) {  // texture.rs:96-117
@@ -517,7 +537,8 @@ DEV f3 refract3(f3 uv, f3 n, float ratio) {  // vec3_helpers.rs:68-75
 DEV float reflectance(float cosine, float ref_index) {  // materials.rs:109-114
     float r0 = (1.0f - ref_index) / (1.0f + ref_index);
     r0 = r0 * r0;
-    return r0 + (1.0f - r0) * powf(1.0f - cosine, 5.0f);
+    float x = 1.0f - cosine, x2 = x * x;  // powf(x, 5.0): within 2 ulp of it, feeds one comparison with a random draw
+    return r0 + (1.0f - r0) * ((x2 * x2) * x);
 }
 // Texture::value of the material's texture.  The commit step folds SolidColor textures into the material
 // record (MF_SOLID: the colour sits in albedo), which saves a dependent texture fetch.

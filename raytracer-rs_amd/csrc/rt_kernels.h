@@ -12,7 +12,7 @@ constexpr int BLOCK = 256;
 // from with ONE atomic per 256 paths; with a single queue that word saturates (about 90 returning
 // atomics per microsecond on one address) and bounds the whole shade step, with 64 words it does not.
 constexpr int NSHARD = 64;
-constexpr int MAX_BLOCKS_PER_SHARD = 32;  // 2048 blocks = 8 per CU; larger queues are grid-strided
+constexpr int MAX_BLOCKS_PER_SHARD = 512;  // upper bound of any grid; launches use the resident block count
 
 // Wavefront path state, structure of arrays, 56 B per path; element (shard s, i) lives at s*cap_shard + i.
 struct PathState {

@@ -14,6 +14,11 @@
 //   split: k_raygen, then k_trace + k_shade per bounce.  The trace kernel then runs at its own (much
 //          smaller) register budget, which pays when traversal dominates.
 // Live paths sit in NSHARD queues (see rt_kernels.h); queue s is served by blocks s, s+NSHARD, ...
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
 #include "rt_devfn.inl"
 
 namespace {
@@ -158,8 +163,10 @@ DEV uint32_t primary_count(uint32_t n, uint32_t s) {
 // Kernels.  Grid = NSHARD * blocks_per_shard; block b serves shard b % NSHARD.
 // =================================================================================
 
+// Held to 128 VGPRs (4 waves per SIMD): one more resident wave than the compiler's own choice hides more of
+// the queue loads and the compaction barrier than the few spilled values cost.
 template <int STACK, bool GROUPS, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(rtk::BLOCK) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
+__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
                                                         rtk::PathState out, rtk::Queues q, uint32_t bounce,
                                                         float4* __restrict__ radiance, unsigned long long* stats,
                                                         uint32_t* overflow_flag) {
@@ -177,25 +184,56 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_bounce(Scene S, rtk::RenderConst
     uint32_t* stk = stack + threadIdx.x;
     TraceCount tc{0u, 0u};
     uint32_t parity = 0;
+    // instrumented build only: wave cycles spent per section (s_memtime ticks), and wave tiles
+    unsigned long long cyc[4] = {0, 0, 0, 0}, tiles = 0, t0 = 0, t1 = 0;
     for (uint32_t base = j0 * rtk::BLOCK; base < n; base += stride * rtk::BLOCK, parity ^= 1u) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false;
         PathRegs p;
+        if (COUNT) t0 = __builtin_amdgcn_s_memtime();
         if (i < n) {
             if (PRIMARY)
                 camera_path(rc, batch, ((base / rtk::BLOCK) * rtk::NSHARD + shard) * rtk::BLOCK + threadIdx.x, p);
             else
                 load_path(in, shard_base + i, p);
+            if (COUNT) {
+                // the section ends when the loaded values are there
+                asm volatile("" ::"v"(p.o.x), "v"(p.d.x), "v"(p.T.x), "v"(p.k0));
+                t1 = __builtin_amdgcn_s_memtime();
+                cyc[0] += t1 - t0;
+                t0 = t1;
+            }
             Hit h;
             trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk,
                                                         overflow_flag, &tc);
+            if (COUNT) {
+                asm volatile("" ::"v"(h.t), "v"(h.prim));
+                t1 = __builtin_amdgcn_s_memtime();
+                cyc[1] += t1 - t0;
+                t0 = t1;
+            }
             alive = shade_path(S, rc, p, h, bounce, radiance);
+            if (COUNT) {
+                asm volatile("" ::"v"(p.o.x), "v"(p.d.x), "v"(p.T.x));
+                t1 = __builtin_amdgcn_s_memtime();
+                cyc[2] += t1 - t0;
+                t0 = t1;
+            }
         }
         compact_store(clds, parity, alive, p, out, out_count, shard_base);
+        if (COUNT) {
+            t1 = __builtin_amdgcn_s_memtime();
+            cyc[3] += t1 - t0;
+            tiles++;
+        }
     }
     if (COUNT) {
         if (tc.nodes) atomicAdd(stats + 1, (unsigned long long)tc.nodes);
         if (tc.prims) atomicAdd(stats + 2, (unsigned long long)tc.prims);
+        if ((threadIdx.x & 63u) == 0 && tiles) {
+            for (int k = 0; k < 4; k++) atomicAdd(stats + 3 + k, cyc[k]);
+            atomicAdd(stats + 7, tiles);
+        }
     }
 }
 
@@ -252,7 +290,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
     }
 }
 
-__global__ __launch_bounds__(rtk::BLOCK) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
+__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
                                                        const float4* __restrict__ hits, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ radiance) {
     __shared__ CompactLds clds;
@@ -370,9 +408,41 @@ inline int grid_flat(unsigned long long n) {
     if (b > (unsigned long long)(rtk::NSHARD * rtk::MAX_BLOCKS_PER_SHARD)) b = rtk::NSHARD * rtk::MAX_BLOCKS_PER_SHARD;
     return (int)b;
 }
-inline int grid_sharded(uint32_t blocks_per_shard) {
+// Upper bound of blocks per shard for kernel `fn` on the current device: resident blocks x oversubscription.
+// Grid size as a multiple of the resident blocks.  Tiles differ a lot in cost (rays that leave the scene at
+// once next to rays that walk the whole tree), and blocks own fixed strides of tiles, so many short blocks
+// balance far better than one round of long ones: measured gains level off near 16.
+int oversubscription() {
+    static const int v = [] {
+        const char* e = getenv("RTAMD_OVERSUB");
+        int k = e ? atoi(e) : 16;
+        return k < 1 ? 1 : (k > 64 ? 64 : k);
+    }();
+    return v;
+}
+uint32_t resident_blocks_per_shard(const void* fn) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, uint32_t> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return rtk::MAX_BLOCKS_PER_SHARD;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({fn, dev});
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    uint32_t lim = rtk::MAX_BLOCKS_PER_SHARD;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::BLOCK, 0) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+        lim = (uint32_t)std::max(1, per_cu * cus * oversubscription() / rtk::NSHARD);
+    else
+        (void)hipGetLastError();
+    if (lim > (uint32_t)rtk::MAX_BLOCKS_PER_SHARD) lim = rtk::MAX_BLOCKS_PER_SHARD;
+    cache[{fn, dev}] = lim;
+    return lim;
+}
+inline int grid_sharded(uint32_t blocks_per_shard, const void* fn) {
+    const uint32_t lim = resident_blocks_per_shard(fn);
     if (blocks_per_shard < 1) blocks_per_shard = 1;
-    if (blocks_per_shard > (uint32_t)rtk::MAX_BLOCKS_PER_SHARD) blocks_per_shard = rtk::MAX_BLOCKS_PER_SHARD;
+    if (blocks_per_shard > lim) blocks_per_shard = lim;
     return (int)(blocks_per_shard * rtk::NSHARD);
 }
 
@@ -413,14 +483,16 @@ namespace rtk {
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q) {
     unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
     uint32_t bps = (uint32_t)((n + (unsigned long long)BLOCK * NSHARD - 1) / ((unsigned long long)BLOCK * NSHARD));
-    hipLaunchKernelGGL(k_raygen, dim3(grid_sharded(bps)), dim3(BLOCK), 0, s, rc, batch, out, q);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_sharded(bps, (const void*)&k_raygen)), dim3(BLOCK), 0, s, rc, batch, out, q);
     return hipGetLastError();
 }
 
 hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, PathState in, Queues q, uint32_t bounce,
                         uint32_t blocks_per_shard, float4* hits, unsigned long long* stats, uint32_t* overflow_flag) {
-    const dim3 grid(grid_sharded(blocks_per_shard)), block(BLOCK);
-#define RT_CALL(N, G, C) hipLaunchKernelGGL((k_trace<N, G, C>), grid, block, 0, s, scene, in, q, bounce, hits, stats, overflow_flag)
+    const dim3 block(BLOCK);
+#define RT_CALL(N, G, C)                                                                                              \
+    hipLaunchKernelGGL((k_trace<N, G, C>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_trace<N, G, C>)), block, 0, s, \
+                       scene, in, q, bounce, hits, stats, overflow_flag)
     RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     return hipGetLastError();
@@ -428,25 +500,25 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
 
 hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc, PathState in, PathState out,
                         const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_sharded(blocks_per_shard)), dim3(BLOCK), 0, s, scene, rc, in, out, hits, q, bounce,
-                       radiance);
+    hipLaunchKernelGGL(k_shade, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade)), dim3(BLOCK), 0, s, scene, rc, in,
+                       out, hits, q, bounce, radiance);
     return hipGetLastError();
 }
 
 hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, const Batch& batch,
                          PathState in, PathState out, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
                          unsigned long long* stats, uint32_t* overflow_flag) {
-    const dim3 grid(grid_sharded(blocks_per_shard)), block(BLOCK);
+    const dim3 block(BLOCK);
     if (bounce == 0) {
-#define RT_CALL(N, G, C)                                                                                                    \
-    hipLaunchKernelGGL((k_bounce<N, G, C, true>), grid, block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, \
-                       overflow_flag)
+#define RT_CALL(N, G, C)                                                                                                       \
+    hipLaunchKernelGGL((k_bounce<N, G, C, true>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<N, G, C, true>)), \
+                       block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
         RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     } else {
-#define RT_CALL(N, G, C)                                                                                                     \
-    hipLaunchKernelGGL((k_bounce<N, G, C, false>), grid, block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, \
-                       overflow_flag)
+#define RT_CALL(N, G, C)                                                                                                         \
+    hipLaunchKernelGGL((k_bounce<N, G, C, false>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<N, G, C, false>)), \
+                       block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
         RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     }
