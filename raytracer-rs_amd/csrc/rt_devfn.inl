@@ -453,6 +453,7 @@ DEV float perlin_turb(const PerlinTable& P, f3 p, int depth) {  // perlin.rs:90-
     float acc = 0.0f;
     f3 temp = p;
     float weight = 1.0f;
+#pragma unroll 1
     for (int i = 0; i < depth; i++) {
         acc = __builtin_fmaf(weight, perlin_noise(P, temp), acc);
         weight *= 0.5f;
@@ -540,27 +541,29 @@ DEV float reflectance(float cosine, float ref_index) {  // materials.rs:109-114
     float x = 1.0f - cosine, x2 = x * x;  // powf(x, 5.0): within 2 ulp of it, feeds one comparison with a random draw
     return r0 + (1.0f - r0) * ((x2 * x2) * x);
 }
-// Texture::value of the material's texture.  The commit step folds SolidColor textures into the material
-// record (MF_SOLID: the colour sits in albedo), which saves a dependent texture fetch.
+// Texture::value of the material's texture (albedo of Lambertian / Isotropic, emission of DiffuseLight); Metal
+// carries its colour in the record.  The commit step folds SolidColor textures into the material record
+// (MF_SOLID: the colour sits in albedo), which saves a dependent texture fetch.  Evaluated once per hit, ahead
+// of the material switch, so that the texture code exists once in the kernel.
 DEV f3 material_color(const Scene& S, const Material& M, const Record& rec) {
-    if (M.pad & MF_SOLID) return ld3(M.albedo);
+    if ((M.pad & MF_SOLID) || M.kind == MK_METAL || M.kind == MK_DIELECTRIC) return ld3(M.albedo);
     return tex_value(S, M.tex, rec.u, rec.v, rec.point);
 }
 // returns true when the path continues; att and the scattered direction are set then
-DEV bool scatter(const Scene& S, const Material& M, f3 wd, const Record& rec, Rng& rng, f3& att, f3& dir) {
+DEV bool scatter(const Material& M, f3 color, f3 wd, const Record& rec, Rng& rng, f3& att, f3& dir) {
     switch (M.kind) {
         case MK_LAMBERTIAN: {  // materials.rs:45-61
             f3 sc = rec.normal + normalize3(rand_in_unit_sphere(rng));
             if (__builtin_fabsf(sc.x) < F32_EPSILON && __builtin_fabsf(sc.y) < F32_EPSILON && __builtin_fabsf(sc.z) < F32_EPSILON)
                 sc = rec.normal;
             dir = sc;
-            att = material_color(S, M, rec);
+            att = color;
             return true;
         }
         case MK_METAL: {  // materials.rs:84-95 (draws even when fuzz == 0)
             f3 reflected = reflect3(normalize3(wd), rec.normal);
             dir = reflected + M.fuzz * rand_in_unit_sphere(rng);
-            att = ld3(M.albedo);
+            att = color;
             return dot3(dir, rec.normal) > 0.0f;
         }
         case MK_DIELECTRIC: {  // materials.rs:117-148
@@ -578,7 +581,7 @@ DEV bool scatter(const Scene& S, const Material& M, f3 wd, const Record& rec, Rn
         }
         case MK_ISOTROPIC: {  // materials.rs:204-215
             dir = normalize3(rand_in_unit_sphere(rng));
-            att = material_color(S, M, rec);
+            att = color;
             return true;
         }
         default:  // MK_LIGHT, materials.rs:176-179

@@ -106,7 +106,8 @@ DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, con
         make_record<false>(S, p.o, p.d, p.time, h, rec);
     Rng rng{p.k0, p.k1, bounce << 24};
     f3 att{1.0f, 1.0f, 1.0f}, dir{0.0f, 0.0f, 0.0f};
-    if (scatter(S, M, p.d, rec, rng, att, dir)) {
+    const f3 color = material_color(S, M, rec);
+    if (scatter(M, color, p.d, rec, rng, att, dir)) {
         if (bounce + 1u >= rc.max_depth) {  // main.rs:45-47: the next ray_color call returns zero
             radiance[p.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             return false;
@@ -117,7 +118,7 @@ DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, con
         return true;
     }
     f3 E{0.0f, 0.0f, 0.0f};  // main.rs:57-59
-    if (M.kind == MK_LIGHT) E = material_color(S, M, rec);
+    if (M.kind == MK_LIGHT) E = color;
     f3 L = p.T * E;
     radiance[p.slot] = make_float4(L.x, L.y, L.z, 0.0f);
     return false;
@@ -166,7 +167,7 @@ DEV uint32_t primary_count(uint32_t n, uint32_t s) {
 // Held to 128 VGPRs (4 waves per SIMD): one more resident wave than the compiler's own choice hides more of
 // the queue loads and the compaction barrier than the few spilled values cost.
 template <int STACK, bool GROUPS, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
+__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : 5))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
                                                         rtk::PathState out, rtk::Queues q, uint32_t bounce,
                                                         float4* __restrict__ radiance, unsigned long long* stats,
                                                         uint32_t* overflow_flag) {
