@@ -806,8 +806,8 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (!c) return RT_ERR_INVALID;
     if (!c->committed) return fail(c, RT_ERR_NOT_COMMITTED, "rt_render before rt_scene_commit");
     if (!cam || !p || !accum_rgb) return fail(c, RT_ERR_INVALID, "rt_render: null argument");
-    if (p->width < 2 || p->height < 2 || (uint64_t)p->width * p->height > (1ull << 31))
-        return fail(c, RT_ERR_INVALID, "rt_render: image size out of range");
+    if (p->width < 2 || p->height < 2 || p->width > 65535 || p->height > 65535 || (uint64_t)p->width * p->height > (1ull << 31))
+        return fail(c, RT_ERR_INVALID, "rt_render: image size out of range (2..65535 per side, at most 2^31 pixels)");
     if (p->sample1 < p->sample0) return fail(c, RT_ERR_INVALID, "rt_render: sample1 < sample0");
     if (p->max_depth == 0 || p->max_depth > 253) return fail(c, RT_ERR_INVALID, "rt_render: max_depth must be 1..253");
     // camera.rs:63 draws the ray time with gen_range(time_start..time_end), which panics on an empty range
@@ -827,6 +827,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         rt_owned_pixels(p->width, p->height, ts, p->rank, nranks, nullptr, 0, &n);
         std::vector<uint32_t> px(n);
         rt_owned_pixels(p->width, p->height, ts, p->rank, nranks, px.data(), n, &n);
+        for (auto& v : px) v = ((v / p->width) << 16) | (v % p->width);  // the kernels want row << 16 | column
         if ((rc = upload(c, c->d_pixels, px.data(), n * sizeof(uint32_t)))) return rc;
         memcpy(c->pixels_key, key, sizeof(key));
         c->n_owned = n;
@@ -875,7 +876,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
             const uint32_t s_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_samples_total, c->capacity / npix));
             for (uint32_t s = 0; s < n_samples_total; s += s_batch) {
                 const uint32_t ns = std::min(s_batch, n_samples_total - s);
-                const rtk::Batch batch{(const uint32_t*)c->d_pixels.p + p0, npix, p->sample0 + s, ns};
+                const rtk::Batch batch{(const uint32_t*)c->d_pixels.p + p0, npix, p->sample0 + s, ns, 1.0 / (double)npix};
                 const uint32_t n_batch = npix * ns;
                 // blocks per shard for the next launches, from the largest queue known so far
                 uint32_t bps = (n_batch + rtk::BLOCK * rtk::NSHARD - 1) / (rtk::BLOCK * rtk::NSHARD);
@@ -917,7 +918,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 }
                 {
                     ScopedTimer tm(c, KS_ACCUM);
-                    HIP_TRY(c, rtk::launch_accumulate(c->stream, (const float4*)c->d_radiance.p, batch, d_accum));
+                    HIP_TRY(c, rtk::launch_accumulate(c->stream, (const float4*)c->d_radiance.p, batch, p->width, d_accum));
                 }
             }
         }

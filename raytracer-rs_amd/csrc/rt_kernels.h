@@ -39,8 +39,9 @@ struct RenderConst {
 
 // one wavefront batch: npix pixels (pixel_list) x n_samples samples starting at sample0
 struct Batch {
-    const uint32_t* pixel_list;
+    const uint32_t* pixel_list;  // owned pixels of this chunk, row << 16 | column
     uint32_t npix, sample0, n_samples;
+    double inv_npix;             // 1.0 / npix
 };
 
 struct TraceCfg {
@@ -65,7 +66,7 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& s
                          uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
                          uint32_t* overflow_flag);
 
-hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, float* accum_rgb);
+hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, uint32_t width, float* accum_rgb);
 hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, uint8_t* out);
 hipError_t launch_intersect_batch(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, uint64_t n,
                                   const float* const rays[7], float tmin, float tmax, uint32_t seed, int32_t* prim,

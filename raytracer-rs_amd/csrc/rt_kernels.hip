@@ -32,15 +32,28 @@ struct PathRegs {
 // Jitter + Camera::get_ray for path slot `slot` of the batch (main.rs:471-474, camera.rs:54-65).
 // slot = sample_local * npix + pixel_local: neighbouring lanes are neighbouring pixels of one tile.
 DEV void camera_path(const rtk::RenderConst& rc, const rtk::Batch& b, uint32_t slot, PathRegs& p) {
-    uint32_t pl = slot % b.npix;
-    uint32_t sample = b.sample0 + slot / b.npix;
-    uint32_t pixel = b.pixel_list[pl];
-    uint32_t i = pixel % rc.width, j = pixel / rc.width;
+    // slot / npix through the f64 reciprocal: the product is within 2^-20 of the quotient, so the truncation is
+    // off by at most one, which the remainder test repairs (an integer divide costs ~30 instructions)
+    uint32_t sl = (uint32_t)((double)slot * b.inv_npix);
+    uint32_t pl = slot - sl * b.npix;
+    if ((int32_t)pl < 0) {
+        sl--;
+        pl += b.npix;
+    } else if (pl >= b.npix) {
+        sl++;
+        pl -= b.npix;
+    }
+    const uint32_t sample = b.sample0 + sl;
+    const uint32_t packed = b.pixel_list[pl];  // row << 16 | column
+    const uint32_t i = packed & 0xFFFFu, j = packed >> 16;
+    const uint32_t pixel = j * rc.width + i;
     Rng rng;
     stream_key(rc.seed, pixel, sample, rng.k0, rng.k1);
     rng.n = CTR_CAMERA;
-    float u = ((float)i + rng.f32()) / (float)(rc.width - 1);
-    float v = ((float)(rc.height - 1 - j) + rng.f32()) / (float)(rc.height - 1);
+    // main.rs:472-473; the denominators are at least 1 and below 2^16, the numerators zero or at least 2^-24
+    const float wd = (float)(rc.width - 1), hd = (float)(rc.height - 1);
+    float u = div_by((float)i + rng.f32(), wd, recip_refined(wd));
+    float v = div_by((float)(rc.height - 1 - j) + rng.f32(), hd, recip_refined(hd));
     // vec3_helpers.rs:47-60: the first point with |p|^2 >= 1 (sic).  The reference draws it even when the
     // aperture is 0 and then scales it by 0; the lens draws have their own counters, so skipping them there
     // changes nothing else.
@@ -319,10 +332,11 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 }
 
 // accum[pixel] += radiance of each sample, in sample order (main.rs:478: reduce(|c, src| c + src))
-__global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restrict__ radiance, rtk::Batch batch,
+__global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restrict__ radiance, rtk::Batch batch, uint32_t width,
                                                             float* __restrict__ accum_rgb) {
     for (uint32_t pl = blockIdx.x * rtk::BLOCK + threadIdx.x; pl < batch.npix; pl += gridDim.x * rtk::BLOCK) {
-        uint32_t pixel = batch.pixel_list[pl];
+        const uint32_t packed = batch.pixel_list[pl];
+        const uint32_t pixel = (packed >> 16) * width + (packed & 0xFFFFu);
         float* a = accum_rgb + 3ull * pixel;
         float r = a[0], g = a[1], b = a[2];
         for (uint32_t s = 0; s < batch.n_samples; s++) {
@@ -526,8 +540,8 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
     return hipGetLastError();
 }
 
-hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, float* accum_rgb) {
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_flat(batch.npix)), dim3(BLOCK), 0, s, radiance, batch, accum_rgb);
+hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, uint32_t width, float* accum_rgb) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_flat(batch.npix)), dim3(BLOCK), 0, s, radiance, batch, width, accum_rgb);
     return hipGetLastError();
 }
 
