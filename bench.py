@@ -57,7 +57,7 @@ def log(*a):
 class Frame:
     """One scene of the workload on this rank: context, camera, accumulation buffer, gather plan."""
 
-    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=32):
+    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=32, gather_on_cpu=False):
         self.name, self.w, self.spp = name, width, spp
         self.h = rtamd.image_height(width, aspect)
         self.rank, self.world = rank, world
@@ -67,15 +67,17 @@ class Frame:
         self.cam = self.ctx.preset_camera(aspect)
         self.accum = torch.zeros((self.h, self.w, 3), dtype=torch.float32, device=f"cuda:{device}")
         self.tile = tile
-        self.gather = TileGather(self.w, self.h, rank, world, self.accum.device, tile) if world > 1 else None
+        # the gloo rehearsal backend has no device collectives: stage the exchange through host memory there
+        self.gather_dev = torch.device("cpu") if gather_on_cpu else self.accum.device
+        self.gather = TileGather(self.w, self.h, rank, world, self.gather_dev, tile) if world > 1 else None
 
-    def render(self, spp=None):
+    def render(self, spp=None, exchange=True):
         self.accum.zero_()
         _, st = self.ctx.render(self.w, self.h, self.cam, spp or self.spp, depth=MAX_DEPTH, seed=1, accum=self.accum,
                                 tile_size=self.tile, rank=self.rank, nranks=self.world)
-        if self.gather is not None:
+        if self.gather is not None and exchange:
             # framebuffer exchange: every rank owns disjoint tiles -> one all_gather of the packed tiles
-            self.frame = self.gather.gather(self.accum)
+            self.frame = self.gather.gather(self.accum.to(self.gather_dev))
         return st
 
     def image(self):
@@ -146,6 +148,9 @@ def main():
     ap.add_argument("--synth-n", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing (roofline becomes null)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo (exchange staged through host memory, ranks may share a GPU) "
+                         "only rehearses the multi-rank path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,17 +158,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            torch.distributed.init_process_group("gloo")
     if args.gpus != world and rank == 0:
         log(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
 
     frames_cfg, width, aspect, spp = WORKLOADS[args.workload]
     width = args.width or width
     spp = args.spp or spp
-    frames = [Frame(n, width, aspect, spp, rank, world, local_rank, args.synth_n) for n in frames_cfg]
+    frames = [Frame(n, width, aspect, spp, rank, world, local_rank, args.synth_n, gather_on_cpu=args.backend == "gloo")
+              for n in frames_cfg]
     for f in frames:
         f.ctx.profile(events=not args.no_profile)
 
@@ -187,7 +198,8 @@ def main():
 
     my_rays = sum(st["rays"] for s in stats for st in s)
     my_paths = sum(st["paths"] for s in stats for st in s)
-    t = torch.tensor([elapsed, float(my_rays), float(my_paths)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    t = torch.tensor([elapsed, float(my_rays), float(my_paths)], dtype=torch.float64,
+                     device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
     if world > 1:
         tmax = t[:1].clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -209,7 +221,7 @@ def main():
             tr_bytes = sh_bytes = bo_bytes = 0.0
             for f, st_frame in zip(frames, zip(*stats)):
                 f.ctx.profile(events=False, count_visits=True)
-                st = f.render(spp=1)
+                st = f.render(spp=1, exchange=False)  # rank 0 alone: no collective here
                 f.ctx.profile(events=True, count_visits=False)
                 nodes_pr = st["node_visits"] / max(st["rays"], 1)
                 prims_pr = st["prim_tests"] / max(st["rays"], 1)

@@ -38,7 +38,8 @@ void rt_ctx_destroy(rt_ctx* ctx);
 const char* rt_last_error(const rt_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
 int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
-/* Upper bound on paths in flight per wavefront batch (default 64Mi paths, about 8 GB of wavefront buffers; env RTAMD_MAX_PATHS_MI). */
+/* Upper bound on paths in flight per wavefront batch (default 512Mi paths = up to 72 GB of wavefront buffers,
+ * never more than 60% of the free device memory; env RTAMD_MAX_PATHS_MI).  A render allocates only what it needs. */
 int rt_ctx_set_max_paths(rt_ctx* ctx, uint64_t max_paths);
 int rt_ctx_synchronize(rt_ctx* ctx);
 /* Kernel pipeline of rt_render: -1 = pick per scene (default), 0 = split (ray generation, then a trace and
