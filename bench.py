@@ -106,6 +106,27 @@ def bounce_bytes_per_ray(primary_frac, alive_frac, nodes_per_ray, prims_per_ray)
             56.0 * alive_frac + 16.0 * (1.0 - alive_frac))
 
 
+def state_bytes_per_ray(primary_frac, alive_frac):
+    """The part of the fused kernel's bytes that must touch HBM even with the whole scene cache-resident: the
+    queue entry read (a primary ray reads its 4-B pixel index instead) and the queue entry or radiance written."""
+    return 56.0 * (1.0 - primary_frac) + 4.0 * primary_frac + 56.0 * alive_frac + 16.0 * (1.0 - alive_frac)
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per step of the dominant kernel from the newest committed PMC summary of this workload
+    (profiles/*_<workload>_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc
+    passes of this script, the read side doubled as gfx950 needs).  None when no summary matches."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob(f"*_{workload}_hbm_traffic.json")):
+        try:
+            doc = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if doc.get("kernel", "").startswith(kernel) and doc.get("bytes_per_step"):
+            best = (doc["bytes_per_step"], f.name)
+    return best
+
+
 def cpu_baseline(frames_cfg, width, aspect, seconds_target=15.0):
     """The CPU oracle (a port of the reference; the Rust binary cannot be built here) on a bounded
     sample of the same workload: the same frames at full resolution and reduced spp, reference-style
@@ -218,7 +239,7 @@ def main():
             shade_ms = sum(st["shade_ms"] for s in stats for st in s)
             bounce_ms = sum(st["bounce_ms"] for s in stats for st in s)
             # per-ray node fetches / primitive tests of this workload: one instrumented pass at 1 spp (untimed)
-            tr_bytes = sh_bytes = bo_bytes = 0.0
+            tr_bytes = sh_bytes = bo_bytes = st_bytes = 0.0
             for f, st_frame in zip(frames, zip(*stats)):
                 f.ctx.profile(events=False, count_visits=True)
                 st = f.render(spp=1, exchange=False)  # rank 0 alone: no collective here
@@ -230,6 +251,7 @@ def main():
                 alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
                 if st_frame[0]["pipeline"] == 1:
                     bo_bytes += f_rays * bounce_bytes_per_ray(f_paths / max(f_rays, 1), alive, nodes_pr, prims_pr)
+                    st_bytes += f_rays * state_bytes_per_ray(f_paths / max(f_rays, 1), alive)
                 else:
                     tr_bytes += f_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
                     sh_bytes += f_rays * shade_bytes_per_ray(alive)
@@ -239,10 +261,15 @@ def main():
             kernel, ms, nbytes, nl = max([("k_trace", trace_ms, tr_bytes, n_tr), ("k_shade", shade_ms, sh_bytes, n_sh),
                                           ("k_bounce", bounce_ms, bo_bytes, n_bo)], key=lambda k: k[1])
             achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            traffic = measured_traffic(args.workload, kernel) if not (args.spp or args.width) else None
             roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 5),
+                    "traffic": round(traffic[0] * args.steps / max(nl, 1), 1) if traffic else None,
+                    "traffic_source": traffic[1] if traffic else None,
                     "launches": int(nl), "avg_launch_ms": round(ms / max(nl, 1), 5),
                     "algorithmic_bytes_per_launch": round(nbytes / max(nl, 1), 1),
+                    # scene data is cache-resident for the reference scenes: the state stream alone, as GB/s
+                    "state_stream_GBps": round(st_bytes / (ms * 1e-3) / 1e9, 2) if kernel == "k_bounce" and ms > 0 else None,
                     "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
                     "bounce_ms_per_step": round(bounce_ms / args.steps, 3)}
         out = {

@@ -2,7 +2,7 @@
 """Turn rocprofv3 output directories into the small summaries kept under profiles/.
 
   summarise_profile.py stats  <dir>/<prefix>_kernel_stats.csv  <out.md>  "<title>" "<command>"
-  summarise_profile.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel-substring>
+  summarise_profile.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel-substring> [steps]
 
 `traffic` adds up FETCH_SIZE and WRITE_SIZE (KiB) over the dispatches whose kernel name contains the
 substring and does not contain the instrumented template flag pattern given by --exclude. gfx950 tallies
@@ -31,7 +31,7 @@ def stats(path, out, title, command):
     open(out, "w").write("\n".join(lines) + "\n")
 
 
-def traffic(fetch_csv, write_csv, out, needle, exclude=None):
+def traffic(fetch_csv, write_csv, out, needle, steps=1, exclude=None):
     def total(path):
         n, s = 0, 0.0
         for r in csv.DictReader(open(path)):
@@ -48,6 +48,7 @@ def traffic(fetch_csv, write_csv, out, needle, exclude=None):
            "FETCH_SIZE_KiB_sum": fetch_kib, "WRITE_SIZE_KiB_sum": write_kib,
            "read_bytes": read_b, "write_bytes": write_b,
            "bytes_per_launch": (read_b / max(nf, 1)) + (write_b / max(nw, 1)),
+           "steps_profiled": steps, "bytes_per_step": (read_b + write_b) / steps,
            "note": "read = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-B requests as 64 B); write = WRITE_SIZE x 1024"}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc))
@@ -57,4 +58,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(*sys.argv[2:6])
     else:
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else None)
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 1)
