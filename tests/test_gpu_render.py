@@ -140,6 +140,19 @@ def test_error_paths(gpu_ctx):
         ctx.render(1, 1, cam, 1)  # width - 1 divides the jitter (main.rs:471)
     with pytest.raises(rtamd.RtError):
         ctx.render(8, 8, cam, 1, depth=0)
+    with pytest.raises(rtamd.RtError):
+        ctx.render(8, 8, cam, 1, depth=254)  # bounce counters 254 and 255 belong to the lens and the camera
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.render(65536, 2, cam, 1)  # pixel coordinates are packed in 16 bits each
+    assert "size" in str(e.value)
+    # gen_range(time_start..time_end) panics on an empty range (camera.rs:63); on the device the redraw
+    # loop would never end, so the call must be refused
+    still = rtamd.camera_new((0, 0, -5), (0, 0, 0), (0, 1, 0), 0.5, 1.0, 0.0, 10.0, 0.5, 0.5)
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.render(8, 8, still, 1)
+    assert "time" in str(e.value)
+    img, st = ctx.render(8, 8, cam, 2, depth=253)
+    assert st["rays"] >= 128 and np.isfinite(img).all()
     ctx.close()
 
 
