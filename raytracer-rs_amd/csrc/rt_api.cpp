@@ -532,6 +532,9 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     std::vector<rtb::Item> top;
     std::vector<uint32_t> media_groups;
     uint32_t blas_depth = 0, n_media = 0, n_inst = 0;
+    // Scenes of a few dozen primitives are traced without the tree (see rtd::Scene::flat): incoherent rays take
+    // different branches of even a four-node tree, which costs more lane time than testing everything in step.
+    bool flat_ok = total_prims <= env_u32("RTAMD_FLAT_MAX", 48);
     // groups first: each gets a contiguous primitive range and (for instances) its own BVH
     for (uint32_t g = 0; g < ng; g++) {
         const rt_group& G = c->groups[g];
@@ -544,8 +547,10 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         D.kind = G.kind;
         D.has_xform = G.has_xform ? 1u : 0u;
         D.root_ref = rtd::REF_EMPTY;
+        D.flat_range = rtd::FLAT_NONE;
         D.order = G.kind == RT_GROUP_MEDIUM ? n_media++ : n_inst++;
         if (mem.empty()) continue;
+        if (mem.size() > 64) flat_ok = false;
         std::vector<rtb::Item> items(mem.size());
         float glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = 0; i < mem.size(); i++) {
@@ -567,6 +572,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         rtb::Result r = rtb::build(items, leaf_max, single, base, nodes, order);
         for (uint32_t oi : order) prims.push_back(make_prim(c, mem[oi], moving));
         D.root_ref = r.root_ref;
+        if (mem.size() <= 64) D.flat_range = base | ((uint32_t)(mem.size() - 1) << 26);
         if (!medium) blas_depth = std::max(blas_depth, r.depth);
         rtb::Item it;
         if (G.has_xform) {
@@ -683,6 +689,9 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.n_prims = (uint32_t)prims.size();
     S.n_groups = ng;
     S.n_media = n_media;
+    S.flat = flat_ok ? 1u : 0u;
+    S.world_first = base;
+    S.world_count = (uint32_t)world.size();
 
     c->info.n_prims = prims.size();
     c->info.n_nodes = nodes.size();

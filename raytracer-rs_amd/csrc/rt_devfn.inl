@@ -264,99 +264,166 @@ DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tmin, float tbest, float& tn) {
 struct TraceCount {
     uint32_t nodes, prims;  // inner nodes fetched, primitive records tested (instrumented builds only)
 };
-template <int STRIDE, int STACK, bool GROUPS, bool COUNT = false>
-DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
-                   uint32_t bounce, Hit& best, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
-    best.t = tmax;
-    best.prim = HIT_NONE;
-    best.grp = -1;
-    best.key = 0;
-    uint32_t cur = S.root_ref;
-    f3 o = wo, d = wd;
-    float a = dot3(d, d);
-    f3 inv = fast_rcp3(d);
-    int grp = -1;
-    int sp = 0;
-    // "while-while": the inner loop walks inner nodes only, so that lanes of a wave that are still
-    // descending do not drag the (long) primitive tests of the others along on every iteration.
-    // cur == REF_EMPTY means this lane has nothing left.
-    for (;;) {
-        while ((cur >> 30) == REF_INNER) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            if (COUNT) cnt->nodes++;
-            float tn0, tn1;
-            bool h0 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, tn0);
-            bool h1 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv, tmin, best.t, tn1);
-            uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-            h0 = h0 && (c0 != REF_EMPTY);
-            h1 = h1 && (c1 != REF_EMPTY);
-            if (h0 || h1) {
-                bool first1 = h1 && (!h0 || tn1 < tn0);
-                cur = first1 ? c1 : c0;
-                if (h0 && h1) {
-                    if (sp < STACK) {
-                        stk[sp * STRIDE] = first1 ? c0 : c1;
-                        sp++;
-                    } else {
-                        *overflow_flag = 1u;
-                    }
-                }
-            } else if (sp > 0) {
-                sp--;
-                cur = stk[sp * STRIDE];
-            } else {
-                cur = REF_EMPTY;
-            }
-        }
-        if (cur == REF_EMPTY) break;
-        const uint32_t type = cur >> 30;
-        if (type == REF_PRIMS) {
-            uint32_t first = cur & 0x03FFFFFFu, n_leaf = ((cur >> 26) & 15u) + 1u;
-            for (uint32_t i = 0; i < n_leaf; i++) test_prim(S, first + i, o, d, a, time, tmin, grp, best);
-            if (COUNT) cnt->prims += n_leaf;
-            cur = REF_EMPTY;
-        } else if (GROUPS && type == REF_INSTANCE) {
-            uint32_t g = cur & 0x3FFFFFFFu;
-            const Group& G = S.groups[g];
-            uint32_t root = G.root_ref;
-            cur = REF_EMPTY;
-            if (root != REF_EMPTY) {
-                if (sp < STACK) {
-                    if (G.has_xform) {  // shapes.rs:66-70
-                        o = xf_point(G.minv, wo);
-                        d = xf_vector(G.minv, wd);
-                        a = dot3(d, d);
-                        inv = fast_rcp3(d);
-                    }
-                    stk[sp * STRIDE] = REF_SENTINEL;
-                    sp++;
-                    grp = (int)g;
-                    cur = root;
+// Traversal state of one ray.  cur == REF_EMPTY with sp == 0 means the walk is over.
+struct Walk {
+    uint32_t cur;
+    int sp;
+    f3 o, d, inv;  // the ray in the space of the subtree being walked (world, or an instance's object space)
+    float a;       // |d|^2
+    int grp;       // instance being walked, or -1
+    Hit best;
+};
+DEV void walk_begin(const Scene& S, Walk& w, f3 wo, f3 wd, float tmax) {
+    w.best.t = tmax;
+    w.best.prim = HIT_NONE;
+    w.best.grp = -1;
+    w.best.key = 0;
+    w.cur = S.root_ref;
+    w.o = wo;
+    w.d = wd;
+    w.a = dot3(wd, wd);
+    w.inv = fast_rcp3(wd);
+    w.grp = -1;
+    w.sp = 0;
+}
+DEV bool walk_done(const Walk& w) { return w.cur == REF_EMPTY; }
+// Walks inner nodes only (at most max_steps of them), until cur is a leaf, an instance, a sentinel or empty.
+// Near child first; a box is entered only if it can still hold a hit at or before the closest one.
+template <int STRIDE, int STACK, bool COUNT>
+DEV void walk_inner(const Scene& S, Walk& w, float tmin, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
+    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) {
+        const float4* np = reinterpret_cast<const float4*>(S.nodes + w.cur);
+        float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        if (COUNT) cnt->nodes++;
+        float tn0, tn1;
+        bool h0 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), w.o, w.inv, tmin, w.best.t, tn0);
+        bool h1 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), w.o, w.inv, tmin, w.best.t, tn1);
+        uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        h0 = h0 && (c0 != REF_EMPTY);
+        h1 = h1 && (c1 != REF_EMPTY);
+        if (h0 || h1) {
+            bool first1 = h1 && (!h0 || tn1 < tn0);
+            w.cur = first1 ? c1 : c0;
+            if (h0 && h1) {
+                if (w.sp < STACK) {
+                    stk[w.sp * STRIDE] = first1 ? c0 : c1;
+                    w.sp++;
                 } else {
                     *overflow_flag = 1u;
                 }
             }
-        } else {  // REF_SENTINEL: the instance's subtree is finished, back to the world ray
-            o = wo;
-            d = wd;
-            a = dot3(d, d);
-            inv = fast_rcp3(d);
-            grp = -1;
-            cur = REF_EMPTY;
-        }
-        if (cur == REF_EMPTY) {  // next entry from the stack
-            if (sp == 0) break;
-            sp--;
-            cur = stk[sp * STRIDE];
+        } else if (w.sp > 0) {
+            w.sp--;
+            w.cur = stk[w.sp * STRIDE];
+        } else {
+            w.cur = REF_EMPTY;
         }
     }
-    // media come after all surfaces, in creation order (the order of a Scene whose media were added last)
-    if (GROUPS)
-        for (uint32_t m = 0; m < S.n_media; m++) {
-            test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
-            if (COUNT) cnt->prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);  // two boundary queries
+}
+// One non-inner step: tests a leaf's primitives, enters an instance or leaves it, then takes the next entry
+// from the stack.  No-op when cur is an inner node or empty.
+template <int STRIDE, int STACK, bool GROUPS, bool COUNT>
+DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin, uint32_t* stk, uint32_t* overflow_flag,
+                   TraceCount* cnt) {
+    const uint32_t type = w.cur >> 30;
+    if (w.cur == REF_EMPTY || type == REF_INNER) return;
+    if (type == REF_PRIMS) {
+        uint32_t first = w.cur & 0x03FFFFFFu, n_leaf = ((w.cur >> 26) & 15u) + 1u;
+        for (uint32_t i = 0; i < n_leaf; i++) test_prim(S, first + i, w.o, w.d, w.a, time, tmin, w.grp, w.best);
+        if (COUNT) cnt->prims += n_leaf;
+        w.cur = REF_EMPTY;
+    } else if (GROUPS && type == REF_INSTANCE) {
+        uint32_t g = w.cur & 0x3FFFFFFFu;
+        const Group& G = S.groups[g];
+        uint32_t root = G.root_ref;
+        w.cur = REF_EMPTY;
+        if (root != REF_EMPTY) {
+            if (w.sp < STACK) {
+                if (G.has_xform) {  // shapes.rs:66-70
+                    w.o = xf_point(G.minv, wo);
+                    w.d = xf_vector(G.minv, wd);
+                    w.a = dot3(w.d, w.d);
+                    w.inv = fast_rcp3(w.d);
+                }
+                stk[w.sp * STRIDE] = REF_SENTINEL;
+                w.sp++;
+                w.grp = (int)g;
+                w.cur = root;
+            } else {
+                *overflow_flag = 1u;
+            }
         }
+    } else {  // REF_SENTINEL: the instance's subtree is finished, back to the world ray
+        w.o = wo;
+        w.d = wd;
+        w.a = dot3(wd, wd);
+        w.inv = fast_rcp3(wd);
+        w.grp = -1;
+        w.cur = REF_EMPTY;
+    }
+    if (w.cur == REF_EMPTY && w.sp > 0) {  // next entry from the stack
+        w.sp--;
+        w.cur = stk[w.sp * STRIDE];
+    }
+}
+// ConstantMedium objects come after all surfaces, in creation order (the order of a Scene whose media were
+// added last), and override the closest surface hit unchecked (scene.rs:33-37).
+template <bool COUNT>
+DEV void apply_media(const Scene& S, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce, Hit& best,
+                     TraceCount* cnt) {
+    for (uint32_t m = 0; m < S.n_media; m++) {
+        test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
+        if (COUNT) cnt->prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);  // two boundary queries
+    }
+}
+// Closest surface hit of one ray in a flat scene (Scene::flat): the world primitives, then each instance's
+// primitives with the ray taken into its object space (shapes.rs:66-70) -- Scene::intersect (scene.rs:27-41)
+// as written, no tree.  Loop counters and addresses are the same in every lane, so the primitive records come
+// through the scalar cache and the wave never splits over which node to visit next.  The closest hit with the
+// "higher id wins a tie" rule does not depend on the test order, so the result equals the tree walk's.
+template <bool GROUPS, bool COUNT>
+DEV void trace_flat(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, Hit& best, TraceCount* cnt) {
+    best.t = tmax;
+    best.prim = HIT_NONE;
+    best.grp = -1;
+    best.key = 0;
+    const float a = dot3(wd, wd);
+    for (uint32_t i = 0; i < S.world_count; i++) test_prim(S, S.world_first + i, wo, wd, a, time, tmin, -1, best);
+    if (COUNT) cnt->prims += S.world_count;
+    if (GROUPS)
+        for (uint32_t g = 0; g < S.n_groups; g++) {
+            const Group& G = S.groups[g];
+            if (G.kind != 1u || G.flat_range == FLAT_NONE) continue;  // media come later; empty instance
+            f3 o = wo, d = wd;
+            float ag = a;
+            if (G.has_xform) {
+                o = xf_point(G.minv, wo);
+                d = xf_vector(G.minv, wd);
+                ag = dot3(d, d);
+            }
+            const uint32_t first = G.flat_range & 0x03FFFFFFu, n = (G.flat_range >> 26) + 1u;
+            for (uint32_t i = 0; i < n; i++) test_prim(S, first + i, o, d, ag, time, tmin, (int)g, best);
+            if (COUNT) cnt->prims += n;
+        }
+}
+// Closest hit of one ray: "while-while" -- the inner loop walks inner nodes only, so that lanes of a wave that
+// are still descending do not drag the (long) primitive tests of the others along on every iteration.
+template <int STRIDE, int STACK, bool GROUPS, bool COUNT = false>
+DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
+                   uint32_t bounce, Hit& best, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
+    if (S.flat) {
+        trace_flat<GROUPS, COUNT>(S, wo, wd, time, tmin, tmax, best, cnt);
+        if (GROUPS) apply_media<COUNT>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
+        return;
+    }
+    Walk w;
+    walk_begin(S, w, wo, wd, tmax);
+    while (!walk_done(w)) {
+        walk_inner<STRIDE, STACK, COUNT>(S, w, tmin, stk, overflow_flag, cnt, 0x7fffffff);
+        walk_leaf<STRIDE, STACK, GROUPS, COUNT>(S, w, wo, wd, time, tmin, stk, overflow_flag, cnt);
+    }
+    best = w.best;
+    if (GROUPS) apply_media<COUNT>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
 }
 
 // ---- hit record (hit_record.rs, shapes.rs) --------------------------------------

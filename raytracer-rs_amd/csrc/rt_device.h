@@ -60,8 +60,9 @@ struct alignas(16) Group {
     uint32_t kind;      // 1 instance, 2 medium
     uint32_t has_xform;
     uint32_t order;     // instance: instance index; medium: medium index (RNG salt, reported id)
-    uint32_t pad;
+    uint32_t flat_range;  // the group's primitives as first | (count-1) << 26, FLAT_NONE when empty or more than 64
 };
+constexpr uint32_t FLAT_NONE = 0xFFFFFFFFu;
 static_assert(sizeof(Group) == 128, "Group must be 128 B");
 
 enum MatKind : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_LIGHT = 3, MK_ISOTROPIC = 4 };
@@ -113,6 +114,9 @@ struct Scene {
     const uint32_t* media;  // group indices of the media, in creation order (evaluated after the BVH walk)
     uint32_t root_ref;
     uint32_t n_prims, n_groups, n_media;
+    // Small scenes skip the tree: every ray tests the world primitives [world_first, world_first + world_count)
+    // and each instance's flat_range in a loop that is uniform over the wave (flat != 0).
+    uint32_t flat, world_first, world_count;
 };
 
 }  // namespace rtd

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
 template <int STACK, bool GROUPS, bool COUNT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
-                                                       uint32_t* overflow_flag) {
+                                                       uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS) {
     __shared__ uint32_t stack[STACK * rtk::BLOCK];
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
@@ -283,20 +283,64 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
     }
     uint32_t* stk = stack + threadIdx.x;
     TraceCount tc{0u, 0u};
-    for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
-        const uint32_t idx = shard_base + i;
-        float4 ot = in.o_time[idx];
-        float4 ds = in.d_slot[idx];
-        uint32_t k0 = 0, k1 = 0;
-        if (GROUPS) {
-            uint2 key = in.key[idx];
-            k0 = key.x;
-            k1 = key.y;
+    if (S.flat) {  // no tree, no divergence between rays: plain strided loop
+        for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
+            const uint32_t at = shard_base + i;
+            const float4 ot = in.o_time[at], ds = in.d_slot[at];
+            Hit h;
+            trace_flat<GROUPS, COUNT>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, h, &tc);
+            hits[at] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), 0.0f);
         }
-        Hit h;
-        trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, k0,
-                                                    k1, bounce, h, stk, overflow_flag, &tc);
-        hits[idx] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), 0.0f);
+        if (COUNT) {
+            if (tc.prims) atomicAdd(stats + 2, (unsigned long long)tc.prims);
+        }
+        return;
+    }
+    // Each wave owns a contiguous run of its shard's queue and keeps its lanes busy across rays: incoherent
+    // rays differ several-fold in how many nodes they visit, and a wave that waits for its longest ray runs at
+    // ~27% lane use.  So a lane whose ray is finished does not wait for the tile: once REFILL lanes are free
+    // (or none is busy), they take the next rays of the run.  Surfaces only: the media are applied by k_shade.
+    const uint32_t nw = stride * (rtk::BLOCK / 64u), wi = j0 * (rtk::BLOCK / 64u) + (threadIdx.x >> 6);
+    const uint32_t per = (((n + nw - 1u) / nw) + 63u) & ~63u;
+    uint32_t next = __builtin_amdgcn_readfirstlane(wi * per);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(next + per < n ? next + per : n);
+    bool have = false;
+    uint32_t idx = 0;
+    f3 wo{0, 0, 0}, wd{0, 0, 0};
+    float time = 0.0f;
+    Walk w;
+    walk_begin(S, w, wo, wd, INF_F);
+    w.cur = REF_EMPTY;
+    uint32_t media_prims = 0;
+    if (COUNT && GROUPS)
+        for (uint32_t m = 0; m < S.n_media; m++) media_prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);
+    for (;;) {
+        const unsigned long long idle = __ballot(!have);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u && next >= end) break;
+        if (next < end && (n_idle >= REFILL || n_idle == 64u)) {
+            const uint32_t mine = next + lane_prefix(idle);
+            next += n_idle;
+            if (!have && mine < end) {
+                idx = shard_base + mine;
+                const float4 ot = in.o_time[idx];
+                const float4 ds = in.d_slot[idx];
+                wo = mk3(ot.x, ot.y, ot.z);
+                wd = mk3(ds.x, ds.y, ds.z);
+                time = ot.w;
+                walk_begin(S, w, wo, wd, INF_F);
+                have = true;
+                if (COUNT) tc.prims += media_prims;
+            }
+        }
+        if (have) {
+            walk_inner<rtk::BLOCK, STACK, COUNT>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
+            walk_leaf<rtk::BLOCK, STACK, GROUPS, COUNT>(S, w, wo, wd, time, 0.005f, stk, overflow_flag, &tc);
+            if (walk_done(w)) {
+                hits[idx] = make_float4(w.best.t, __uint_as_float(w.best.prim), __int_as_float(w.best.grp), 0.0f);
+                have = false;
+            }
+        }
     }
     if (COUNT) {
         if (tc.nodes) atomicAdd(stats + 1, (unsigned long long)tc.nodes);
@@ -325,6 +369,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             h.prim = __float_as_uint(hv.y);
             h.grp = __float_as_int(hv.z);
             h.key = 0;
+            if (S.n_media) apply_media<false>(S, p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h, nullptr);
             alive = shade_path(S, rc, p, h, bounce, radiance);
         }
         compact_store(clds, parity, alive, p, out, out_count, shard_base);
@@ -423,39 +468,45 @@ inline int grid_flat(unsigned long long n) {
     if (b > (unsigned long long)(rtk::NSHARD * rtk::MAX_BLOCKS_PER_SHARD)) b = rtk::NSHARD * rtk::MAX_BLOCKS_PER_SHARD;
     return (int)b;
 }
-// Upper bound of blocks per shard for kernel `fn` on the current device: resident blocks x oversubscription.
 // Grid size as a multiple of the resident blocks.  Tiles differ a lot in cost (rays that leave the scene at
 // once next to rays that walk the whole tree), and blocks own fixed strides of tiles, so many short blocks
-// balance far better than one round of long ones: measured gains level off near 16.
+// balance far better than one round of long ones: measured gains level off near 16.  The trace kernel of the
+// split pipeline balances inside each wave instead and wants long runs per wave: 2.
+int env_factor(const char* name, int dflt) {
+    const char* e = getenv(name);
+    int k = e ? atoi(e) : dflt;
+    return k < 1 ? 1 : (k > 64 ? 64 : k);
+}
 int oversubscription() {
-    static const int v = [] {
-        const char* e = getenv("RTAMD_OVERSUB");
-        int k = e ? atoi(e) : 16;
-        return k < 1 ? 1 : (k > 64 ? 64 : k);
-    }();
+    static const int v = env_factor("RTAMD_OVERSUB", 16);
     return v;
 }
-uint32_t resident_blocks_per_shard(const void* fn) {
+int trace_oversubscription() {
+    static const int v = env_factor("RTAMD_TRACE_OVERSUB", 2);
+    return v;
+}
+// Blocks of kernel `fn` that are resident at once on the current device.
+uint32_t resident_blocks(const void* fn) {
     static std::mutex mu;
     static std::map<std::pair<const void*, int>, uint32_t> cache;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return rtk::MAX_BLOCKS_PER_SHARD;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find({fn, dev});
     if (it != cache.end()) return it->second;
     int per_cu = 0, cus = 0;
-    uint32_t lim = rtk::MAX_BLOCKS_PER_SHARD;
+    uint32_t n = 1024;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::BLOCK, 0) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
-        lim = (uint32_t)std::max(1, per_cu * cus * oversubscription() / rtk::NSHARD);
+        n = (uint32_t)(per_cu * cus);
     else
         (void)hipGetLastError();
-    if (lim > (uint32_t)rtk::MAX_BLOCKS_PER_SHARD) lim = rtk::MAX_BLOCKS_PER_SHARD;
-    cache[{fn, dev}] = lim;
-    return lim;
+    cache[{fn, dev}] = n;
+    return n;
 }
-inline int grid_sharded(uint32_t blocks_per_shard, const void* fn) {
-    const uint32_t lim = resident_blocks_per_shard(fn);
+inline int grid_sharded(uint32_t blocks_per_shard, const void* fn, int oversub) {
+    uint32_t lim = std::max<uint32_t>(1u, resident_blocks(fn) * (uint32_t)oversub / rtk::NSHARD);
+    if (lim > (uint32_t)rtk::MAX_BLOCKS_PER_SHARD) lim = rtk::MAX_BLOCKS_PER_SHARD;
     if (blocks_per_shard < 1) blocks_per_shard = 1;
     if (blocks_per_shard > lim) blocks_per_shard = lim;
     return (int)(blocks_per_shard * rtk::NSHARD);
@@ -498,7 +549,7 @@ namespace rtk {
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q) {
     unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
     uint32_t bps = (uint32_t)((n + (unsigned long long)BLOCK * NSHARD - 1) / ((unsigned long long)BLOCK * NSHARD));
-    hipLaunchKernelGGL(k_raygen, dim3(grid_sharded(bps, (const void*)&k_raygen)), dim3(BLOCK), 0, s, rc, batch, out, q);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_sharded(bps, (const void*)&k_raygen, oversubscription())), dim3(BLOCK), 0, s, rc, batch, out, q);
     return hipGetLastError();
 }
 
@@ -506,8 +557,9 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
                         uint32_t blocks_per_shard, float4* hits, unsigned long long* stats, uint32_t* overflow_flag) {
     const dim3 block(BLOCK);
 #define RT_CALL(N, G, C)                                                                                              \
-    hipLaunchKernelGGL((k_trace<N, G, C>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_trace<N, G, C>)), block, 0, s, \
-                       scene, in, q, bounce, hits, stats, overflow_flag)
+    hipLaunchKernelGGL((k_trace<N, G, C>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_trace<N, G, C>, trace_oversubscription())), block, 0, s, \
+                       scene, in, q, bounce, hits, stats, overflow_flag, (uint32_t)env_factor("RTAMD_REFILL", 24),      \
+                       env_factor("RTAMD_INNER_STEPS", 4))
     RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     return hipGetLastError();
@@ -515,7 +567,7 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
 
 hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc, PathState in, PathState out,
                         const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade)), dim3(BLOCK), 0, s, scene, rc, in,
+    hipLaunchKernelGGL(k_shade, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade, oversubscription())), dim3(BLOCK), 0, s, scene, rc, in,
                        out, hits, q, bounce, radiance);
     return hipGetLastError();
 }
@@ -526,13 +578,13 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
     const dim3 block(BLOCK);
     if (bounce == 0) {
 #define RT_CALL(N, G, C)                                                                                                       \
-    hipLaunchKernelGGL((k_bounce<N, G, C, true>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<N, G, C, true>)), \
+    hipLaunchKernelGGL((k_bounce<N, G, C, true>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<N, G, C, true>, oversubscription())), \
                        block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
         RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     } else {
 #define RT_CALL(N, G, C)                                                                                                         \
-    hipLaunchKernelGGL((k_bounce<N, G, C, false>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<N, G, C, false>)), \
+    hipLaunchKernelGGL((k_bounce<N, G, C, false>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<N, G, C, false>, oversubscription())), \
                        block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
         RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
