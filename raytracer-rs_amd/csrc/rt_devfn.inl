@@ -212,6 +212,8 @@ DEV bool list_closest(const Scene& S, uint32_t ref, f3 o, f3 d, float a, float t
     return any;
 }
 
+DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tmin, float tbest, float& tn);
+DEV f3 fast_rcp3(f3 d);
 // ConstantMedium::intersect (shapes.rs:648-701).  wo/wd: the world ray.  A medium that reports a hit
 // replaces the closest hit so far unchecked, as Scene::intersect does (scene.rs:33-37): its final_t may
 // lie beyond best.t because shapes.rs:676-683 divides by the ray length twice.
@@ -223,6 +225,10 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
         o = xf_point(G.minv, wo);
         d = xf_vector(G.minv, wd);
     }
+    // The first boundary query runs over the whole line (shapes.rs:655); a line that misses the widened box
+    // of the boundary misses every primitive of it, so the exact tests are skipped for it.
+    float tn_unused;
+    if (!slab(ld3(G.blo), ld3(G.bhi), o, fast_rcp3(d), -INF_F, INF_F, tn_unused)) return;
     float a = dot3(d, d);
     float r1, r2;
     if (!list_closest(S, G.root_ref, o, d, a, time, -INF_F, INF_F, r1)) return;

@@ -61,9 +61,11 @@ struct alignas(16) Group {
     uint32_t has_xform;
     uint32_t order;     // instance: instance index; medium: medium index (RNG salt, reported id)
     uint32_t flat_range;  // the group's primitives as first | (count-1) << 26, FLAT_NONE when empty or more than 64
+    float blo[3], bhi[3]; // widened box of the group's primitives in the group's own space (culls medium queries)
+    uint32_t pad[2];
 };
 constexpr uint32_t FLAT_NONE = 0xFFFFFFFFu;
-static_assert(sizeof(Group) == 128, "Group must be 128 B");
+static_assert(sizeof(Group) == 160, "Group must be 160 B");
 
 enum MatKind : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_LIGHT = 3, MK_ISOTROPIC = 4 };
 // flags the commit step writes into Material::pad
