@@ -124,7 +124,7 @@ int rt_scene_commit(rt_ctx* ctx, float shutter_t0, float shutter_t1);
 typedef struct rt_scene_info {
     uint64_t n_prims, n_nodes, n_groups, n_media;
     uint32_t max_depth;    /* deepest stack the traversal can need */
-    uint32_t stack_entries; /* entries per lane the kernels were specialised for */
+    uint32_t stack_entries; /* traversal stack entries per lane the kernels are launched with (1 for flat scenes) */
     uint64_t device_bytes;
     double build_seconds;
 } rt_scene_info;

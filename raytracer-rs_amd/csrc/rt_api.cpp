@@ -612,7 +612,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
 
     uint32_t need = top_r.depth + (n_inst ? 1 + blas_depth : 0) + 1;
     if (need > 64) return fail(c, RT_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack");
-    c->stack_entries = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+    c->stack_entries = (int)(flat_ok ? 1u : need);
     c->has_groups = ng > 0;
 
     // upload
@@ -696,6 +696,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.n_groups = ng;
     S.n_media = n_media;
     S.flat = flat_ok ? 1u : 0u;
+    S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
     S.world_first = base;
     S.world_count = (uint32_t)world.size();
 

@@ -295,7 +295,7 @@ DEV void walk_begin(const Scene& S, Walk& w, f3 wo, f3 wd, float tmax) {
 DEV bool walk_done(const Walk& w) { return w.cur == REF_EMPTY; }
 // Walks inner nodes only (at most max_steps of them), until cur is a leaf, an instance, a sentinel or empty.
 // Near child first; a box is entered only if it can still hold a hit at or before the closest one.
-template <int STRIDE, int STACK, bool COUNT>
+template <int STRIDE, bool COUNT>
 DEV void walk_inner(const Scene& S, Walk& w, float tmin, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
     for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) {
         const float4* np = reinterpret_cast<const float4*>(S.nodes + w.cur);
@@ -311,7 +311,7 @@ DEV void walk_inner(const Scene& S, Walk& w, float tmin, uint32_t* stk, uint32_t
             bool first1 = h1 && (!h0 || tn1 < tn0);
             w.cur = first1 ? c1 : c0;
             if (h0 && h1) {
-                if (w.sp < STACK) {
+                if (w.sp < (int)S.stack_cap) {
                     stk[w.sp * STRIDE] = first1 ? c0 : c1;
                     w.sp++;
                 } else {
@@ -328,7 +328,7 @@ DEV void walk_inner(const Scene& S, Walk& w, float tmin, uint32_t* stk, uint32_t
 }
 // One non-inner step: tests a leaf's primitives, enters an instance or leaves it, then takes the next entry
 // from the stack.  No-op when cur is an inner node or empty.
-template <int STRIDE, int STACK, bool GROUPS, bool COUNT>
+template <int STRIDE, bool GROUPS, bool COUNT>
 DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin, uint32_t* stk, uint32_t* overflow_flag,
                    TraceCount* cnt) {
     const uint32_t type = w.cur >> 30;
@@ -344,7 +344,7 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
         uint32_t root = G.root_ref;
         w.cur = REF_EMPTY;
         if (root != REF_EMPTY) {
-            if (w.sp < STACK) {
+            if (w.sp < (int)S.stack_cap) {
                 if (G.has_xform) {  // shapes.rs:66-70
                     w.o = xf_point(G.minv, wo);
                     w.d = xf_vector(G.minv, wd);
@@ -414,7 +414,7 @@ DEV void trace_flat(const Scene& S, f3 wo, f3 wd, float time, float tmin, float 
 }
 // Closest hit of one ray: "while-while" -- the inner loop walks inner nodes only, so that lanes of a wave that
 // are still descending do not drag the (long) primitive tests of the others along on every iteration.
-template <int STRIDE, int STACK, bool GROUPS, bool COUNT = false>
+template <int STRIDE, bool GROUPS, bool COUNT = false>
 DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
                    uint32_t bounce, Hit& best, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
     if (S.flat) {
@@ -425,8 +425,8 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
     Walk w;
     walk_begin(S, w, wo, wd, tmax);
     while (!walk_done(w)) {
-        walk_inner<STRIDE, STACK, COUNT>(S, w, tmin, stk, overflow_flag, cnt, 0x7fffffff);
-        walk_leaf<STRIDE, STACK, GROUPS, COUNT>(S, w, wo, wd, time, tmin, stk, overflow_flag, cnt);
+        walk_inner<STRIDE, COUNT>(S, w, tmin, stk, overflow_flag, cnt, 0x7fffffff);
+        walk_leaf<STRIDE, GROUPS, COUNT>(S, w, wo, wd, time, tmin, stk, overflow_flag, cnt);
     }
     best = w.best;
     if (GROUPS) apply_media<COUNT>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);

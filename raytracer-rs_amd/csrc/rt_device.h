@@ -119,6 +119,7 @@ struct Scene {
     // Small scenes skip the tree: every ray tests the world primitives [world_first, world_first + world_count)
     // and each instance's flat_range in a loop that is uniform over the wave (flat != 0).
     uint32_t flat, world_first, world_count;
+    uint32_t stack_cap;  // entries of the per-lane traversal stack the kernels are launched with (LDS, dynamic)
 };
 
 }  // namespace rtd

@@ -45,7 +45,7 @@ struct Batch {
 };
 
 struct TraceCfg {
-    int stack_entries;  // 16, 32 or 64: per-lane traversal stack in LDS
+    int stack_entries;  // per-lane traversal stack in LDS (Scene::stack_cap)
     bool has_groups;    // scene holds instances / media
     bool count_visits;  // instrumented traversal (node / primitive counters)
 };

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <tuple>
 
 #include "rt_devfn.inl"
 
@@ -179,12 +180,12 @@ DEV uint32_t primary_count(uint32_t n, uint32_t s) {
 
 // Held to 128 VGPRs (4 waves per SIMD): one more resident wave than the compiler's own choice hides more of
 // the queue loads and the compaction barrier than the few spilled values cost.
-template <int STACK, bool GROUPS, bool COUNT, bool PRIMARY>
+template <bool GROUPS, bool COUNT, bool PRIMARY>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : 5))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
                                                         rtk::PathState out, rtk::Queues q, uint32_t bounce,
                                                         float4* __restrict__ radiance, unsigned long long* stats,
                                                         uint32_t* overflow_flag) {
-    __shared__ uint32_t stack[STACK * rtk::BLOCK];
+    extern __shared__ uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
     __shared__ CompactLds clds;
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n_batch = batch.npix * batch.n_samples;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
                 t0 = t1;
             }
             Hit h;
-            trace_ray<rtk::BLOCK, STACK, GROUPS, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk,
+            trace_ray<rtk::BLOCK, GROUPS, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk,
                                                         overflow_flag, &tc);
             if (COUNT) {
                 asm volatile("" ::"v"(h.t), "v"(h.prim));
@@ -269,11 +270,11 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
     }
 }
 
-template <int STACK, bool GROUPS, bool COUNT>
+template <bool GROUPS, bool COUNT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
                                                        uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS) {
-    __shared__ uint32_t stack[STACK * rtk::BLOCK];
+    extern __shared__ uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     const uint32_t shard_base = shard * q.cap_shard;
@@ -334,8 +335,8 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
             }
         }
         if (have) {
-            walk_inner<rtk::BLOCK, STACK, COUNT>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
-            walk_leaf<rtk::BLOCK, STACK, GROUPS, COUNT>(S, w, wo, wd, time, 0.005f, stk, overflow_flag, &tc);
+            walk_inner<rtk::BLOCK, COUNT>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
+            walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, wo, wd, time, 0.005f, stk, overflow_flag, &tc);
             if (walk_done(w)) {
                 hits[idx] = make_float4(w.best.t, __uint_as_float(w.best.prim), __int_as_float(w.best.grp), 0.0f);
                 have = false;
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_resolve(const float* __restrict_
     }
 }
 
-template <int STACK, bool GROUPS>
+template <bool GROUPS>
 __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigned long long n, const float* __restrict__ ox,
                                                                  const float* __restrict__ oy, const float* __restrict__ oz,
                                                                  const float* __restrict__ dx, const float* __restrict__ dy,
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
                                                                  float tmin, float tmax, uint32_t seed, int32_t* prim,
                                                                  int32_t* inst, float* t, float* normal, uint8_t* front,
                                                                  float* uv, float* point, uint32_t* overflow_flag) {
-    __shared__ uint32_t stack[STACK * rtk::BLOCK];
+    extern __shared__ uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
     uint32_t* stk = stack + threadIdx.x;
     for (unsigned long long i = (unsigned long long)blockIdx.x * rtk::BLOCK + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * rtk::BLOCK) {
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
         uint32_t k0, k1;
         stream_key(seed, (uint32_t)i, 0u, k0, k1);
         Hit h;
-        trace_ray<rtk::BLOCK, STACK, GROUPS>(S, wo, wd, time, tmin, tmax, k0, k1, 0u, h, stk, overflow_flag);
+        trace_ray<rtk::BLOCK, GROUPS>(S, wo, wd, time, tmin, tmax, k0, k1, 0u, h, stk, overflow_flag);
         bool hit = h.prim != HIT_NONE;
         Record rec;
         rec.point = {0, 0, 0};
@@ -486,26 +487,26 @@ int trace_oversubscription() {
     return v;
 }
 // Blocks of kernel `fn` that are resident at once on the current device.
-uint32_t resident_blocks(const void* fn) {
+uint32_t resident_blocks(const void* fn, size_t smem) {
     static std::mutex mu;
-    static std::map<std::pair<const void*, int>, uint32_t> cache;
+    static std::map<std::tuple<const void*, int, size_t>, uint32_t> cache;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find({fn, dev});
+    auto it = cache.find(std::make_tuple(fn, dev, smem));
     if (it != cache.end()) return it->second;
     int per_cu = 0, cus = 0;
     uint32_t n = 1024;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::BLOCK, 0) == hipSuccess &&
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::BLOCK, smem) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
         n = (uint32_t)(per_cu * cus);
     else
         (void)hipGetLastError();
-    cache[{fn, dev}] = n;
+    cache[std::make_tuple(fn, dev, smem)] = n;
     return n;
 }
-inline int grid_sharded(uint32_t blocks_per_shard, const void* fn, int oversub) {
-    uint32_t lim = std::max<uint32_t>(1u, resident_blocks(fn) * (uint32_t)oversub / rtk::NSHARD);
+inline int grid_sharded(uint32_t blocks_per_shard, const void* fn, int oversub, size_t smem = 0) {
+    uint32_t lim = std::max<uint32_t>(1u, resident_blocks(fn, smem) * (uint32_t)oversub / rtk::NSHARD);
     if (lim > (uint32_t)rtk::MAX_BLOCKS_PER_SHARD) lim = rtk::MAX_BLOCKS_PER_SHARD;
     if (blocks_per_shard < 1) blocks_per_shard = 1;
     if (blocks_per_shard > lim) blocks_per_shard = lim;
@@ -516,35 +517,20 @@ inline int grid_sharded(uint32_t blocks_per_shard, const void* fn, int oversub) 
 
 namespace rtk {
 
-// stack size x groups x instrumented -> template instance
-#define RT_DISPATCH_TRACE_CFG(cfg, CALL)                       \
-    do {                                                       \
-        if ((cfg).stack_entries <= 16) {                       \
-            if ((cfg).has_groups) {                            \
-                if ((cfg).count_visits) CALL(16, true, true);  \
-                else CALL(16, true, false);                    \
-            } else {                                           \
-                if ((cfg).count_visits) CALL(16, false, true); \
-                else CALL(16, false, false);                   \
-            }                                                  \
-        } else if ((cfg).stack_entries <= 32) {                \
-            if ((cfg).has_groups) {                            \
-                if ((cfg).count_visits) CALL(32, true, true);  \
-                else CALL(32, true, false);                    \
-            } else {                                           \
-                if ((cfg).count_visits) CALL(32, false, true); \
-                else CALL(32, false, false);                   \
-            }                                                  \
-        } else {                                               \
-            if ((cfg).has_groups) {                            \
-                if ((cfg).count_visits) CALL(64, true, true);  \
-                else CALL(64, true, false);                    \
-            } else {                                           \
-                if ((cfg).count_visits) CALL(64, false, true); \
-                else CALL(64, false, false);                   \
-            }                                                  \
-        }                                                      \
+// groups x instrumented -> template instance
+#define RT_DISPATCH_TRACE_CFG(cfg, CALL)                \
+    do {                                                \
+        if ((cfg).has_groups) {                         \
+            if ((cfg).count_visits) CALL(true, true);   \
+            else CALL(true, false);                     \
+        } else {                                        \
+            if ((cfg).count_visits) CALL(false, true);  \
+            else CALL(false, false);                    \
+        }                                               \
     } while (0)
+
+// LDS bytes of the per-lane traversal stacks of one block
+inline size_t stack_bytes(const Scene& scene) { return (size_t)std::max(1u, scene.stack_cap) * BLOCK * sizeof(uint32_t); }
 
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q) {
     unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
@@ -556,9 +542,11 @@ hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batc
 hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, PathState in, Queues q, uint32_t bounce,
                         uint32_t blocks_per_shard, float4* hits, unsigned long long* stats, uint32_t* overflow_flag) {
     const dim3 block(BLOCK);
-#define RT_CALL(N, G, C)                                                                                              \
-    hipLaunchKernelGGL((k_trace<N, G, C>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_trace<N, G, C>, trace_oversubscription())), block, 0, s, \
-                       scene, in, q, bounce, hits, stats, overflow_flag, (uint32_t)env_factor("RTAMD_REFILL", 24),      \
+    const size_t smem = stack_bytes(scene);
+#define RT_CALL(G, C)                                                                                                       \
+    hipLaunchKernelGGL((k_trace<G, C>),                                                                                     \
+                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C>, trace_oversubscription(), smem)), block, \
+                       smem, s, scene, in, q, bounce, hits, stats, overflow_flag, (uint32_t)env_factor("RTAMD_REFILL", 24), \
                        env_factor("RTAMD_INNER_STEPS", 4))
     RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
@@ -576,16 +564,19 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
                          PathState in, PathState out, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
                          unsigned long long* stats, uint32_t* overflow_flag) {
     const dim3 block(BLOCK);
+    const size_t smem = stack_bytes(scene);
     if (bounce == 0) {
-#define RT_CALL(N, G, C)                                                                                                       \
-    hipLaunchKernelGGL((k_bounce<N, G, C, true>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<N, G, C, true>, oversubscription())), \
-                       block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
+#define RT_CALL(G, C)                                                                                                     \
+    hipLaunchKernelGGL((k_bounce<G, C, true>),                                                                            \
+                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, true>, oversubscription(), smem)), block, \
+                       smem, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
         RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     } else {
-#define RT_CALL(N, G, C)                                                                                                         \
-    hipLaunchKernelGGL((k_bounce<N, G, C, false>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<N, G, C, false>, oversubscription())), \
-                       block, 0, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
+#define RT_CALL(G, C)                                                                                                      \
+    hipLaunchKernelGGL((k_bounce<G, C, false>),                                                                            \
+                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, false>, oversubscription(), smem)), block, \
+                       smem, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
         RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     }
@@ -609,9 +600,9 @@ hipError_t launch_intersect_batch(hipStream_t s, const TraceCfg& cfg, const Scen
     const dim3 grid(grid_flat(n)), block(BLOCK);
     TraceCfg c = cfg;
     c.count_visits = false;
-#define RT_CALL(N, G, C)                                                                                                      \
-    hipLaunchKernelGGL((k_intersect_batch<N, G>), grid, block, 0, s, scene, (unsigned long long)n, rays[0], rays[1], rays[2], \
-                       rays[3], rays[4], rays[5], rays[6], tmin, tmax, seed, prim, inst, t, normal, front, uv, point,        \
+#define RT_CALL(G, C)                                                                                                          \
+    hipLaunchKernelGGL((k_intersect_batch<G>), grid, block, stack_bytes(scene), s, scene, (unsigned long long)n, rays[0], rays[1], \
+                       rays[2], rays[3], rays[4], rays[5], rays[6], tmin, tmax, seed, prim, inst, t, normal, front, uv, point,  \
                        overflow_flag)
     RT_DISPATCH_TRACE_CFG(c, RT_CALL);
 #undef RT_CALL
