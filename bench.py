@@ -84,32 +84,41 @@ class Frame:
         return self.frame if self.gather is not None else self.accum
 
 
+L2_PER_XCD = 4 << 20  # a scene below this stays resident in every XCD's L2 for a whole launch
+
+
+def scene_bytes_per_ray(info, nodes_per_ray, prims_per_ray):
+    """Algorithmic HBM bytes a ray needs from the scene description: 64 B per inner node fetched (two child boxes
+    + two references) and 32 B per primitive record tested -- unless the whole scene fits the 4 MiB L2 of an XCD.
+    Then the launch reads it from HBM once per XCD and every further visit is a cache hit by construction
+    (that part is added per launch, see scene_bytes_per_launch), so nothing is charged per ray."""
+    if info["device_bytes"] <= L2_PER_XCD:
+        return 0.0
+    return 64.0 * nodes_per_ray + 32.0 * prims_per_ray
+
+
+def scene_bytes_per_launch(info):
+    return 8.0 * info["device_bytes"] if info["device_bytes"] <= L2_PER_XCD else 0.0
+
+
 def trace_bytes_per_ray(info, nodes_per_ray, prims_per_ray):
-    """Algorithmic bytes one ray moves through k_trace: its state in (origin+time 16 B, direction+slot
-    16 B; scenes with media also key 8 B + meta 16 B), its hit record out (16 B), 64 B per inner node
-    fetched (two child boxes + two references) and 32 B per primitive record tested."""
-    state = 32 + 16 + (24 if info["n_groups"] else 0)
-    return state + 64.0 * nodes_per_ray + 32.0 * prims_per_ray
+    """Algorithmic bytes one ray moves through k_trace: its ray in (origin+time 16 B, direction+slot 16 B), its
+    hit record out (16 B), and the scene bytes of scene_bytes_per_ray."""
+    return 32 + 16 + scene_bytes_per_ray(info, nodes_per_ray, prims_per_ray)
 
 
 def shade_bytes_per_ray(alive_frac):
-    """k_shade: path state in (56 B) + hit record (16 B) + primitive (32 B) + material (32 B) + texture
-    (32 B); out: the compacted state of surviving paths (56 B) or the radiance of ended ones (16 B)."""
-    return 56 + 16 + 32 + 32 + 32 + 56.0 * alive_frac + 16.0 * (1.0 - alive_frac)
+    """k_shade: path state in (56 B) + hit record (16 B); out: the compacted state of surviving paths (56 B) or
+    the radiance of ended ones (16 B).  The hit primitive, material and texture records are cache hits."""
+    return 56 + 16 + 56.0 * alive_frac + 16.0 * (1.0 - alive_frac)
 
 
-def bounce_bytes_per_ray(primary_frac, alive_frac, nodes_per_ray, prims_per_ray):
-    """k_bounce (fused pipeline): path state in (56 B; a primary ray reads only its 4-B pixel index), 64 B per
-    inner node fetched, 32 B per primitive record tested, the hit primitive (32 B) and its material (32 B)
-    for shading; out: the compacted state of a surviving path (56 B) or the radiance of an ended one (16 B)."""
-    return (56.0 * (1.0 - primary_frac) + 4.0 * primary_frac + 64.0 * nodes_per_ray + 32.0 * prims_per_ray + 64.0 +
+def bounce_bytes_per_ray(info, primary_frac, alive_frac, nodes_per_ray, prims_per_ray):
+    """k_bounce (fused pipeline): path state in (56 B; a primary ray reads only its 4-B pixel index), the scene
+    bytes of scene_bytes_per_ray; out: the compacted state of a surviving path (56 B) or the radiance of an
+    ended one (16 B)."""
+    return (56.0 * (1.0 - primary_frac) + 4.0 * primary_frac + scene_bytes_per_ray(info, nodes_per_ray, prims_per_ray) +
             56.0 * alive_frac + 16.0 * (1.0 - alive_frac))
-
-
-def state_bytes_per_ray(primary_frac, alive_frac):
-    """The part of the fused kernel's bytes that must touch HBM even with the whole scene cache-resident: the
-    queue entry read (a primary ray reads its 4-B pixel index instead) and the queue entry or radiance written."""
-    return 56.0 * (1.0 - primary_frac) + 4.0 * primary_frac + 56.0 * alive_frac + 16.0 * (1.0 - alive_frac)
 
 
 def measured_traffic(workload, kernel):
@@ -239,7 +248,7 @@ def main():
             shade_ms = sum(st["shade_ms"] for s in stats for st in s)
             bounce_ms = sum(st["bounce_ms"] for s in stats for st in s)
             # per-ray node fetches / primitive tests of this workload: one instrumented pass at 1 spp (untimed)
-            tr_bytes = sh_bytes = bo_bytes = st_bytes = 0.0
+            tr_bytes = sh_bytes = bo_bytes = 0.0
             for f, st_frame in zip(frames, zip(*stats)):
                 f.ctx.profile(events=False, count_visits=True)
                 st = f.render(spp=1, exchange=False)  # rank 0 alone: no collective here
@@ -250,10 +259,11 @@ def main():
                 f_paths = sum(s["paths"] for s in st_frame)
                 alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
                 if st_frame[0]["pipeline"] == 1:
-                    bo_bytes += f_rays * bounce_bytes_per_ray(f_paths / max(f_rays, 1), alive, nodes_pr, prims_pr)
-                    st_bytes += f_rays * state_bytes_per_ray(f_paths / max(f_rays, 1), alive)
+                    bo_bytes += f_rays * bounce_bytes_per_ray(f.info, f_paths / max(f_rays, 1), alive, nodes_pr, prims_pr)
+                    bo_bytes += scene_bytes_per_launch(f.info) * sum(s["bounce_kernel_launches"] for s in st_frame)
                 else:
                     tr_bytes += f_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
+                    tr_bytes += scene_bytes_per_launch(f.info) * sum(s["trace_launches"] for s in st_frame)
                     sh_bytes += f_rays * shade_bytes_per_ray(alive)
             n_tr = sum(st["trace_launches"] for s in stats for st in s)
             n_sh = sum(st["shade_launches"] for s in stats for st in s)
@@ -268,8 +278,9 @@ def main():
                     "traffic_source": traffic[1] if traffic else None,
                     "launches": int(nl), "avg_launch_ms": round(ms / max(nl, 1), 5),
                     "algorithmic_bytes_per_launch": round(nbytes / max(nl, 1), 1),
-                    # scene data is cache-resident for the reference scenes: the state stream alone, as GB/s
-                    "state_stream_GBps": round(st_bytes / (ms * 1e-3) / 1e9, 2) if kernel == "k_bounce" and ms > 0 else None,
+                    # True: the scene fits an XCD's L2, so per-ray node/primitive fetches are cache hits and only the
+                    # path-state stream (plus one scene read per XCD and launch) is charged to HBM
+                    "scene_resident_in_l2": all(f.info["device_bytes"] <= L2_PER_XCD for f in frames),
                     "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
                     "bounce_ms_per_step": round(bounce_ms / args.steps, 3)}
         out = {

@@ -11,8 +11,9 @@
 // Two pipelines share the device functions of rt_devfn.inl:
 //   fused: one k_bounce launch per bounce.  A ray's state is read once and written once per bounce, the
 //          hit record never touches memory and bounce 0 generates its camera rays in registers.
-//   split: k_raygen, then k_trace + k_shade per bounce.  The trace kernel then runs at its own (much
-//          smaller) register budget, which pays when traversal dominates.
+//   split: k_raygen, then k_trace + k_shade per bounce.  k_trace keeps persistent waves busy across rays
+//          (free lanes take the next rays of the wave's run), which pays when rays walk deep trees.
+// Scenes of a few dozen primitives are traced without the tree in both (trace_flat).
 // Live paths sit in NSHARD queues (see rt_kernels.h); queue s is served by blocks s, s+NSHARD, ...
 #include <algorithm>
 #include <cstdlib>
