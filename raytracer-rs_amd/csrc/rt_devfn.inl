@@ -212,6 +212,81 @@ DEV bool list_closest(const Scene& S, uint32_t ref, f3 o, f3 d, float a, float t
     return any;
 }
 
+// The candidate distances of one primitive without any [tmin, tmax]: bit 0 of the result says c0 exists (a
+// rect's plane hit inside its bounds, a sphere's near root), bit 1 that c1 exists (the sphere's far root).
+// The values are the ones prim_candidate computes; pick_root applies its range logic to them.
+DEV uint32_t prim_roots(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time, float& c0, float& c1) {
+    const float4* pp = reinterpret_cast<const float4*>(S.prims + pi);
+    float4 A = pp[0];
+    float4 B = pp[1];
+    uint32_t kind = __float_as_uint(B.y) & 7u;
+    c0 = 0.0f;
+    c1 = 0.0f;
+    if (kind <= PK_MOVING_SPHERE) {  // shapes.rs:117-139, 195-217
+        f3 c{A.x, A.y, A.z};
+        if (kind == PK_MOVING_SPHERE) c = moving_center(S, c, __float_as_uint(B.w), time);
+        float r = A.w;
+        f3 oc = o - c;
+        float half_b = dot3(oc, d);
+        float cc = dot3(oc, oc) - r * r;
+        float disc = half_b * half_b - a * cc;
+        if (disc < 0.0f) return 0u;
+        float sq = __builtin_sqrtf(disc);
+        c0 = (-half_b - sq) / a;
+        c1 = (-half_b + sq) / a;
+        return 3u;
+    }
+    int ax = kind == PK_RECT_XY ? 2 : (kind == PK_RECT_XZ ? 1 : 0);  // shapes.rs:279-292, 343-356, 407-420
+    int a0 = ax == 0 ? 1 : 0;
+    int a1 = ax == 2 ? 1 : 2;
+    float t = (A.x - comp(o, ax)) / comp(d, ax);
+    float x = comp(o, a0) + t * comp(d, a0);
+    float y = comp(o, a1) + t * comp(d, a1);
+    if (x < A.y || x > A.w || y < A.z || y > B.x) return 0u;
+    c0 = t;
+    return 1u;
+}
+DEV bool pick_root(uint32_t have, float c0, float c1, float tmin, float tmax, float& t) {
+    if (!(have & 1u)) return false;
+    t = c0;
+    if (t < tmin || t > tmax) {
+        if (!(have & 2u)) return false;
+        t = c1;
+        if (t < tmin || t > tmax) return false;
+    }
+    return true;
+}
+// The two boundary queries of ConstantMedium::intersect (shapes.rs:655-664) over a list of at most 8
+// primitives: Scene::intersect twice (scene.rs:27-41, the closest hit so far narrows the range), the second
+// time from r1 + 0.0001 on.  Both queries look at the same candidate distances, so those are computed once.
+DEV bool boundary_pair(const Scene& S, uint32_t first, uint32_t cnt, f3 o, f3 d, float a, float time, float& r1, float& r2) {
+    float c0[8], c1[8];
+    uint32_t have[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; i++) have[i] = i < cnt ? prim_roots(S, first + i, o, d, a, time, c0[i], c1[i]) : 0u;
+    float closest = INF_F, t;
+    bool any = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; i++)
+        if (pick_root(have[i], c0[i], c1[i], -INF_F, closest, t)) {
+            closest = t;
+            any = true;
+        }
+    if (!any) return false;
+    r1 = closest;
+    const float from = r1 + 0.0001f;
+    closest = INF_F;
+    any = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; i++)
+        if (pick_root(have[i], c0[i], c1[i], from, closest, t)) {
+            closest = t;
+            any = true;
+        }
+    r2 = closest;
+    return any;
+}
+
 DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tmin, float tbest, float& tn);
 DEV f3 fast_rcp3(f3 d);
 // ConstantMedium::intersect (shapes.rs:648-701).  wo/wd: the world ray.  A medium that reports a hit
@@ -231,8 +306,13 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     if (!slab(ld3(G.blo), ld3(G.bhi), o, fast_rcp3(d), -INF_F, INF_F, tn_unused)) return;
     float a = dot3(d, d);
     float r1, r2;
-    if (!list_closest(S, G.root_ref, o, d, a, time, -INF_F, INF_F, r1)) return;
-    if (!list_closest(S, G.root_ref, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
+    const uint32_t first = G.root_ref & 0x03FFFFFFu, cnt = ((G.root_ref >> 26) & 15u) + 1u;
+    if (cnt <= 8u) {
+        if (!boundary_pair(S, first, cnt, o, d, a, time, r1, r2)) return;
+    } else {
+        if (!list_closest(S, G.root_ref, o, d, a, time, -INF_F, INF_F, r1)) return;
+        if (!list_closest(S, G.root_ref, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
+    }
     if (r1 < tmin) r1 = tmin;
     if (r2 > best.t) r2 = best.t;
     if (r1 >= r2) return;
