@@ -258,13 +258,17 @@ def main():
                 f_rays = sum(s["rays"] for s in st_frame)
                 f_paths = sum(s["paths"] for s in st_frame)
                 alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
-                if st_frame[0]["pipeline"] == 1:
-                    bo_bytes += f_rays * bounce_bytes_per_ray(f.info, f_paths / max(f_rays, 1), alive, nodes_pr, prims_pr)
+                mode = st_frame[0]["pipeline"]  # 0 split, 1 fused, 2 hybrid: camera rays fused, scattered rays split
+                fused_rays = f_rays if mode == 1 else (f_paths if mode == 2 else 0)
+                split_rays = f_rays - fused_rays
+                if fused_rays:
+                    primary = f_paths / max(fused_rays, 1)
+                    bo_bytes += fused_rays * bounce_bytes_per_ray(f.info, primary, alive, nodes_pr, prims_pr)
                     bo_bytes += scene_bytes_per_launch(f.info) * sum(s["bounce_kernel_launches"] for s in st_frame)
-                else:
-                    tr_bytes += f_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
+                if split_rays:
+                    tr_bytes += split_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
                     tr_bytes += scene_bytes_per_launch(f.info) * sum(s["trace_launches"] for s in st_frame)
-                    sh_bytes += f_rays * shade_bytes_per_ray(alive)
+                    sh_bytes += split_rays * shade_bytes_per_ray(alive)
             n_tr = sum(st["trace_launches"] for s in stats for st in s)
             n_sh = sum(st["shade_launches"] for s in stats for st in s)
             n_bo = sum(st["bounce_kernel_launches"] for s in stats for st in s)

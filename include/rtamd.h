@@ -43,7 +43,8 @@ int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
 int rt_ctx_set_max_paths(rt_ctx* ctx, uint64_t max_paths);
 int rt_ctx_synchronize(rt_ctx* ctx);
 /* Kernel pipeline of rt_render: -1 = pick per scene (default), 0 = split (ray generation, then a trace and
- * a shade kernel per bounce), 1 = fused (one kernel per bounce).  Both produce the same bits. */
+ * a shade kernel per bounce), 1 = fused (one kernel per bounce), 2 = hybrid (bounce 0 fused, later bounces
+ * split).  All produce the same bits. */
 int rt_ctx_set_pipeline(rt_ctx* ctx, int pipeline);
 
 /* ---- scene description --------------------------------------------------
@@ -182,7 +183,7 @@ typedef struct rt_render_stats {
     uint64_t prim_tests;  /* primitive records tested  (profile flag 2) */
     double bounce_ms;     /* fused pipeline: HIP-event time of the bounce kernel (profile flag 1) */
     uint64_t bounce_kernel_launches;
-    uint32_t pipeline;    /* 1 = fused (one kernel per bounce), 0 = split (raygen, then trace + shade per bounce) */
+    uint32_t pipeline;    /* the pipeline used: 0 split, 1 fused, 2 hybrid (see rt_ctx_set_pipeline) */
     uint32_t reserved;
 } rt_render_stats;
 

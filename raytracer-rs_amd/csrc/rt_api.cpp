@@ -79,8 +79,9 @@ struct rt_ctx {
     uint64_t max_paths = 512ull << 20;
     uint64_t capacity = 0;
     uint32_t cap_shard = 0;
-    int pipeline = -1;  // -1 choose per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce)
-    uint64_t fused_node_limit = 1024;  // scenes with more BVH nodes than this take the split pipeline
+    int pipeline = -1;  // -1 choose per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce), 2 hybrid
+    int deep_pipeline = 2;  // what trees above fused_node_limit take
+    uint64_t fused_node_limit = 64;  // scenes with more BVH nodes than this take deep_pipeline
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
     uint64_t n_owned = 0;
@@ -323,7 +324,8 @@ int rt_ctx_create(int device, rt_ctx** out) {
         return RT_ERR_HIP;
     }
     c->max_paths = (uint64_t)env_u32("RTAMD_MAX_PATHS_MI", 512) << 20;
-    if (getenv("RTAMD_PIPELINE")) c->pipeline = (int)env_u32("RTAMD_PIPELINE", 1) ? 1 : 0;  // 0 split, 1 fused
+    if (getenv("RTAMD_PIPELINE")) c->pipeline = (int)std::min(env_u32("RTAMD_PIPELINE", 1), 2u);  // 0 split, 1 fused, 2 hybrid
+    if (getenv("RTAMD_DEEP_PIPELINE")) c->deep_pipeline = (int)std::min(env_u32("RTAMD_DEEP_PIPELINE", 2), 2u);
     if (getenv("RTAMD_FUSED_NODE_LIMIT")) c->fused_node_limit = env_u32("RTAMD_FUSED_NODE_LIMIT", 0);
     *out = c;
     return RT_OK;
@@ -360,7 +362,7 @@ int rt_ctx_set_max_paths(rt_ctx* c, uint64_t max_paths) {
     return RT_OK;
 }
 int rt_ctx_set_pipeline(rt_ctx* c, int pipeline) {
-    if (!c || pipeline < -1 || pipeline > 1) return fail(c, RT_ERR_INVALID, "pipeline must be -1, 0 or 1");
+    if (!c || pipeline < -1 || pipeline > 2) return fail(c, RT_ERR_INVALID, "pipeline must be -1, 0, 1 or 2");
     c->pipeline = pipeline;
     return RT_OK;
 }
@@ -875,8 +877,12 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     // Pipeline choice: the fused bounce kernel moves the least data and wins while a ray visits few nodes
     // (flat scenes, random_world's 370 nodes).  Deeper trees take the split pipeline, whose trace kernel keeps
     // its lanes busy across rays at half the registers: final_scene (1.9k nodes) +9%, 10M spheres +55%.
-    const bool fused = c->pipeline >= 0 ? c->pipeline == 1 : c->info.n_nodes <= c->fused_node_limit;
-    st.pipeline = fused ? 1u : 0u;
+    // mode 2 (hybrid): camera rays are coherent and cost no queue read, so bounce 0 runs fused; the scattered
+    // rays of the later bounces go through the split kernels
+    const int mode = c->pipeline >= 0 ? c->pipeline : (c->info.n_nodes <= c->fused_node_limit ? 1 : c->deep_pipeline);
+    // (flat scenes have no nodes to speak of and always fall on the fused side)
+    const bool fused = mode == 1;
+    st.pipeline = (uint32_t)mode;
     if (n_owned && n_samples_total) {
         uint64_t cap = std::min<uint64_t>(c->max_paths, n_owned * (uint64_t)n_samples_total);
         if (cap > c->capacity) {
@@ -912,7 +918,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 uint32_t bps = (n_batch + rtk::BLOCK * rtk::NSHARD - 1) / (rtk::BLOCK * rtk::NSHARD);
                 st.batches++;
                 st.paths += n_batch;
-                if (fused) {
+                if (mode != 0) {
                     HIP_TRY(c, hipMemsetAsync(q.counts, 0, 3 * rtk::NSHARD * sizeof(uint32_t), c->stream));
                 } else {
                     ScopedTimer tm(c, KS_RAYGEN);
@@ -920,7 +926,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 }
                 for (uint32_t b = 0; b < p->max_depth; b++) {
                     const rtk::PathState in = path_state(c, b & 1), out = path_state(c, (b & 1) ^ 1);
-                    if (fused) {
+                    if (fused || (mode == 2 && b == 0)) {
                         ScopedTimer tm(c, KS_BOUNCE);
                         HIP_TRY(c, rtk::launch_bounce(c->stream, tcfg, c->scene, rcst, batch, in, out, q, b, bps, d_rad, d_stats, d_ovf));
                     } else {

@@ -13,7 +13,7 @@ for name, w, aspect, spp in cases:
     h = rtamd.image_height(w, aspect)
     cam = ctx.preset_camera(aspect)
     acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
-    for pipe in (0, 1):
+    for pipe in (0, 1, 2):
         ctx.set_pipeline(pipe)
         ctx.render(w, h, cam, 4, accum=acc)
         ctx.profile(events=True)
@@ -24,7 +24,7 @@ for name, w, aspect, spp in cases:
         ctx.profile(events=False)
         acc.zero_()
         t0 = time.perf_counter(); _, s2 = ctx.render(w, h, cam, spp, accum=acc); dt = time.perf_counter() - t0
-        print(f"{name:20s} {'fused' if pipe else 'split'} {w}x{h}x{spp} rays {st['rays']/1e6:8.1f}M r/p {st['rays']/st['paths']:.2f} | {dt*1e3:8.2f} ms = {s2['rays']/dt/1e6:8.1f} Mrays/s | "
+        print(f"{name:20s} {('split', 'fused', 'hybrd')[pipe]} {w}x{h}x{spp} rays {st['rays']/1e6:8.1f}M r/p {st['rays']/st['paths']:.2f} | {dt*1e3:8.2f} ms = {s2['rays']/dt/1e6:8.1f} Mrays/s | "
               f"trace {st['trace_ms']:7.2f} shade {st['shade_ms']:7.2f} bounce {st['bounce_ms']:7.2f} raygen {st['raygen_ms']:6.2f} accum {st['accumulate_ms']:6.2f} | batches {st['batches']} launches {st['bounce_launches']} | "
               f"nodes/ray {sc['node_visits']/sc['rays']:.2f} prims/ray {sc['prim_tests']/sc['rays']:.2f} | nodes {info['n_nodes']}", flush=True)
     ctx.close()

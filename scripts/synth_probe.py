@@ -10,7 +10,7 @@ t0 = time.perf_counter()
 info = ctx.load_scene("synth_spheres", seed=1, n_synth=n)
 print("load+commit %.2f s" % (time.perf_counter() - t0), {k: info[k] for k in ("n_prims", "n_nodes", "max_depth", "stack_entries", "device_bytes", "build_seconds")}, flush=True)
 cam = ctx.preset_camera(aspect)
-for pipe in (0, 1):
+for pipe in (0, 1, 2):
     ctx.set_pipeline(pipe)
     ctx.profile(True, False)
     acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")

@@ -257,14 +257,14 @@ def test_fused_and_split_pipelines_give_the_same_bits(name):
     ctx.load_scene(name, seed=1)
     cam = ctx.preset_camera(w / h)
     out = {}
-    for pipe in (0, 1):
+    for pipe in (0, 1, 2):  # split, fused, hybrid (fused camera rays, split scattered rays)
         ctx.set_pipeline(pipe)
         img, st = ctx.render(w, h, cam, spp, seed=9)
         assert st["pipeline"] == pipe
         out[pipe] = (img, st["rays"])
     ctx.close()
-    assert out[0][1] == out[1][1]
-    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1] == out[2][1]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
 
 
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "two_spheres", "simple_light"])
