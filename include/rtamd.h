@@ -46,6 +46,9 @@ int rt_ctx_synchronize(rt_ctx* ctx);
  * a shade kernel per bounce), 1 = fused (one kernel per bounce), 2 = hybrid (bounce 0 fused, later bounces
  * split).  All produce the same bits. */
 int rt_ctx_set_pipeline(rt_ctx* ctx, int pipeline);
+/* Once a batch has at most tail_paths live paths, one kernel launch walks each of them to its end instead of
+ * one launch per bounce (default 262144, env RTAMD_TAIL_PATHS; 0 = never).  The image does not depend on it. */
+int rt_ctx_set_tail_paths(rt_ctx* ctx, uint64_t tail_paths);
 
 /* ---- scene description --------------------------------------------------
  * Replaces the object graph of Arc<dyn Hittable>/Arc<dyn Material>/Arc<dyn Texture>
@@ -184,7 +187,9 @@ typedef struct rt_render_stats {
     double bounce_ms;     /* fused pipeline: HIP-event time of the bounce kernel (profile flag 1) */
     uint64_t bounce_kernel_launches;
     uint32_t pipeline;    /* the pipeline used: 0 split, 1 fused, 2 hybrid (see rt_ctx_set_pipeline) */
-    uint32_t reserved;
+    uint32_t tail_launches; /* batches whose last live paths were finished by the single-launch tail kernel */
+    uint64_t tail_rays;   /* rays traced by the tail kernel (included in rays) */
+    double tail_ms;       /* HIP-event time of the tail kernel (profile flag 1) */
 } rt_render_stats;
 
 int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* accum_rgb,

@@ -46,7 +46,7 @@ struct HostImage {
     std::vector<uint8_t> rgb;
 };
 
-enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_BOUNCE = 4, KS_COUNT = 5 };
+enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_BOUNCE = 4, KS_TAIL = 5, KS_COUNT = 6 };
 
 }  // namespace
 
@@ -82,6 +82,7 @@ struct rt_ctx {
     int pipeline = -1;  // -1 choose per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce), 2 hybrid
     int deep_pipeline = 2;  // what trees above fused_node_limit take
     uint64_t fused_node_limit = 64;  // scenes with more BVH nodes than this take deep_pipeline
+    uint64_t tail_paths = 256u << 10;  // a batch with at most this many live paths is finished by one k_finish launch
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
     uint64_t n_owned = 0;
@@ -327,6 +328,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (getenv("RTAMD_PIPELINE")) c->pipeline = (int)std::min(env_u32("RTAMD_PIPELINE", 1), 2u);  // 0 split, 1 fused, 2 hybrid
     if (getenv("RTAMD_DEEP_PIPELINE")) c->deep_pipeline = (int)std::min(env_u32("RTAMD_DEEP_PIPELINE", 2), 2u);
     if (getenv("RTAMD_FUSED_NODE_LIMIT")) c->fused_node_limit = env_u32("RTAMD_FUSED_NODE_LIMIT", 0);
+    if (getenv("RTAMD_TAIL_PATHS")) c->tail_paths = env_u32("RTAMD_TAIL_PATHS", 0);
     *out = c;
     return RT_OK;
 }
@@ -364,6 +366,11 @@ int rt_ctx_set_max_paths(rt_ctx* c, uint64_t max_paths) {
 int rt_ctx_set_pipeline(rt_ctx* c, int pipeline) {
     if (!c || pipeline < -1 || pipeline > 2) return fail(c, RT_ERR_INVALID, "pipeline must be -1, 0, 1 or 2");
     c->pipeline = pipeline;
+    return RT_OK;
+}
+int rt_ctx_set_tail_paths(rt_ctx* c, uint64_t tail_paths) {
+    if (!c) return RT_ERR_INVALID;
+    c->tail_paths = tail_paths;
     return RT_OK;
 }
 int rt_ctx_synchronize(rt_ctx* c) {
@@ -947,9 +954,20 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                                                   hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(c, hipStreamSynchronize(c->stream));
                         uint32_t longest = 0;
-                        for (int k = 0; k < rtk::NSHARD; k++) longest = std::max(longest, c->h_counts[k]);
+                        uint64_t live = 0;
+                        for (int k = 0; k < rtk::NSHARD; k++) {
+                            longest = std::max(longest, c->h_counts[k]);
+                            live += c->h_counts[k];
+                        }
                         if (longest == 0) break;
                         bps = (longest + rtk::BLOCK - 1) / rtk::BLOCK;
+                        if (live <= c->tail_paths && !c->count_visits) {
+                            // few paths left: one launch walks each of them to its end (same draws, same bits)
+                            ScopedTimer tm(c, KS_TAIL);
+                            HIP_TRY(c, rtk::launch_finish(c->stream, tcfg, c->scene, rcst, out, q, b + 1, bps, d_rad, d_stats, d_ovf));
+                            st.tail_launches++;
+                            break;
+                        }
                     }
                 }
                 {
@@ -964,7 +982,8 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (!accum_dev) HIP_TRY(c, hipMemcpyAsync(accum_rgb, d_accum, accum_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_owned && n_samples_total) {
-        st.rays = c->h_rays[0];
+        st.tail_rays = c->h_rays[8];
+        st.rays = c->h_rays[0] + st.tail_rays;
         st.node_visits = c->h_rays[1];
         st.prim_tests = c->h_rays[2];
         if (c->count_visits && getenv("RTAMD_SECTION_CYCLES")) {
@@ -978,7 +997,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     }
     if (c->profile) {
-        double ms[KS_COUNT] = {0, 0, 0, 0, 0};
+        double ms[KS_COUNT] = {0, 0, 0, 0, 0, 0};
         for (auto& u : c->ev_used) {
             float t = 0;
             if (hipEventElapsedTime(&t, c->ev_pool[u.second.first], c->ev_pool[u.second.second]) == hipSuccess) ms[u.first] += t;
@@ -991,6 +1010,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         st.shade_ms = ms[KS_SHADE];
         st.accumulate_ms = ms[KS_ACCUM];
         st.bounce_ms = ms[KS_BOUNCE];
+        st.tail_ms = ms[KS_TAIL];
     }
     st.render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = st;

@@ -50,8 +50,9 @@ struct TraceCfg {
     bool count_visits;  // instrumented traversal (node / primitive counters)
 };
 
-// stats: three 64-bit words: [0] += rays traced; with count_visits also [1] += inner nodes fetched,
-// [2] += primitive records tested.
+// stats: 64-bit words: [0] += rays traced by the per-bounce kernels; with count_visits also [1] += inner nodes
+// fetched, [2] += primitive records tested ([3..7]: section cycles of the instrumented fused kernel);
+// [8] += rays traced by the tail kernel.
 
 // ---- split pipeline: raygen, then per bounce trace + shade --------------------------------------------
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q);
@@ -64,6 +65,10 @@ hipError_t launch_shade(hipStream_t s, const rtd::Scene& scene, const RenderCons
 hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc,
                          const Batch& batch, PathState in, PathState out, Queues q, uint32_t bounce,
                          uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
+                         uint32_t* overflow_flag);
+// ---- tail: every queued path of bounce `bounce` is walked to its end by one lane -----------------------------
+hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc, PathState in,
+                         Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
                          uint32_t* overflow_flag);
 
 hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, uint32_t width, float* accum_rgb);

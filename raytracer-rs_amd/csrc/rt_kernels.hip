@@ -4,6 +4,7 @@
 //   k_raygen           camera samples -> path state            (main.rs:471-474, camera.rs:54-65)
 //   k_trace            closest hit of every live path          (bvh_node.rs:145-164 + shapes.rs intersect fns)
 //   k_shade            hit record, emitted, scatter, compaction (main.rs:44-63, materials.rs, texture.rs)
+//   k_finish           the last few live paths, each walked to its end by one lane (no queue, no launches)
 //   k_accumulate       per-pixel sum in sample order            (main.rs:478-481)
 //   k_resolve          quantise                                 (main.rs:307-313)
 //   k_intersect_batch  hit() path on caller-supplied rays
@@ -378,6 +379,34 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
     }
 }
 
+// Tail of a batch.  Once only a few paths are alive a bounce costs a launch (and now and then a host
+// read-back of the queue lengths) rather than work, so the remaining paths are finished here in one go:
+// each lane takes one queued path and runs the ray_color loop (main.rs:44-63) to its end.  A path's draws
+// are keyed by (stream, bounce), so the result is the one the bounce-per-launch kernels would have produced.
+template <bool GROUPS>
+__global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::Queues q,
+                                                        uint32_t bounce, float4* __restrict__ radiance,
+                                                        unsigned long long* stats, uint32_t* overflow_flag) {
+    extern __shared__ uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
+    const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
+    const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
+    const uint32_t shard_base = shard * q.cap_shard;
+    uint32_t* stk = stack + threadIdx.x;
+    uint32_t rays = 0;
+    for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
+        PathRegs p;
+        load_path(in, shard_base + i, p);
+        for (uint32_t b = bounce;; b++) {  // shade_path ends the path at the depth limit at the latest
+            Hit h;
+            trace_ray<rtk::BLOCK, GROUPS, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, b, h, stk, overflow_flag, nullptr);
+            rays++;
+            if (!shade_path(S, rc, p, h, b, radiance)) break;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(stats + 8, (unsigned long long)rays);
+}
+
 // accum[pixel] += radiance of each sample, in sample order (main.rs:478: reduce(|c, src| c + src))
 __global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restrict__ radiance, rtk::Batch batch, uint32_t width,
                                                             float* __restrict__ accum_rgb) {
@@ -581,6 +610,20 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
         RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, PathState in, Queues q,
+                         uint32_t bounce, uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
+                         uint32_t* overflow_flag) {
+    const size_t smem = stack_bytes(scene);
+    if (blocks_per_shard < 1) blocks_per_shard = 1;
+    if (blocks_per_shard > (uint32_t)MAX_BLOCKS_PER_SHARD) blocks_per_shard = MAX_BLOCKS_PER_SHARD;
+    const dim3 grid(blocks_per_shard * NSHARD), block(BLOCK);
+    if (cfg.has_groups)
+        hipLaunchKernelGGL((k_finish<true>), grid, block, smem, s, scene, rc, in, q, bounce, radiance, stats, overflow_flag);
+    else
+        hipLaunchKernelGGL((k_finish<false>), grid, block, smem, s, scene, rc, in, q, bounce, radiance, stats, overflow_flag);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPP
 # every symbol include/rtamd.h declares
 ABI_SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_ctx_set_stream", "rt_ctx_set_max_paths",
-    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
+    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
     "rt_resolve_u8", "rt_owned_pixels")
@@ -62,7 +62,7 @@ class rt_render_stats(C.Structure):
                 ("raygen_ms", C.c_double), ("accumulate_ms", C.c_double), ("trace_launches", C.c_uint64),
                 ("shade_launches", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
                 ("bounce_ms", C.c_double), ("bounce_kernel_launches", C.c_uint64), ("pipeline", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("tail_launches", C.c_uint32), ("tail_rays", C.c_uint64), ("tail_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -119,6 +119,7 @@ def core():
     L.rt_ctx_set_max_paths.argtypes = [vp, u64]
     L.rt_ctx_synchronize.argtypes = [vp]
     L.rt_ctx_set_pipeline.argtypes = [vp, C.c_int]
+    L.rt_ctx_set_tail_paths.argtypes = [vp, u64]
     L.rt_scene_clear.argtypes = [vp]
     L.rt_scene_set_spheres.argtypes = [vp, u32] + [vp] * 7
     L.rt_scene_set_rects.argtypes = [vp, u32] + [vp] * 6
@@ -272,6 +273,10 @@ class Context:
     def set_pipeline(self, pipeline):
         """-1 pick per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce)."""
         self._check(self.L.rt_ctx_set_pipeline(self.h, pipeline))
+
+    def set_tail_paths(self, n):
+        """Live-path count at or below which one launch finishes a batch (0 = one launch per bounce to the end)."""
+        self._check(self.L.rt_ctx_set_tail_paths(self.h, n))
 
     def synchronize(self):
         self._check(self.L.rt_ctx_synchronize(self.h))

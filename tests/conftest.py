@@ -16,5 +16,8 @@ def pytest_configure(config):
 def gpu_ctx():
     import rtamd
     ctx = rtamd.Context(0)
+    # test frames are small: keep the one-launch-per-bounce kernels in play for most of each path's life and
+    # leave only the last few thousand paths to the tail kernel (the default threshold would hand it everything)
+    ctx.set_tail_paths(4096)
     yield ctx
     ctx.close()

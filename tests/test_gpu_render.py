@@ -254,6 +254,7 @@ def test_rank_split_sample_split_and_batch_size_change_no_bit(gpu_ctx):
 def test_fused_and_split_pipelines_give_the_same_bits(name):
     w, h, spp = 150, 100, 5
     ctx = rtamd.Context(0)
+    ctx.set_tail_paths(2048)
     ctx.load_scene(name, seed=1)
     cam = ctx.preset_camera(w / h)
     out = {}
@@ -267,6 +268,30 @@ def test_fused_and_split_pipelines_give_the_same_bits(name):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
 
 
+@pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "earth"])
+def test_tail_kernel_changes_no_bit(name):
+    """The last live paths of a batch are walked to their end by one launch (k_finish) instead of one launch per
+    bounce.  Where the hand-over happens must not matter: never, after the first bounce, or somewhere in between."""
+    w, h, spp = 160, 100, 6
+    ctx = rtamd.Context(0)
+    ctx.load_scene(name, seed=1)
+    cam = ctx.preset_camera(w / h)
+    out = []
+    for tail in (0, 3000, 1 << 30):
+        ctx.set_tail_paths(tail)
+        for pipe in (1, 2):
+            ctx.set_pipeline(pipe)
+            img, st = ctx.render(w, h, cam, spp, seed=11)
+            if tail != 3000:  # (a closed box can keep more than 3000 paths alive down to the depth limit)
+                assert (st["tail_launches"] > 0) == (tail > 0) and (st["tail_rays"] > 0) == (tail > 0)
+            if tail == 1 << 30:  # everything but the camera rays went through the tail
+                assert st["bounce_launches"] == 1 and st["tail_rays"] == st["rays"] - st["paths"]
+            out.append((img, st["rays"]))
+    ctx.close()
+    for img, rays in out[1:]:
+        assert rays == out[0][1] and np.array_equal(img, out[0][0])
+
+
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "two_spheres", "simple_light"])
 def test_flat_and_tree_tracing_give_the_same_bits(name, monkeypatch):
     """Scenes of a few dozen primitives are traced without the tree (uniform loops over the primitives).  The
@@ -278,6 +303,7 @@ def test_flat_and_tree_tracing_give_the_same_bits(name, monkeypatch):
     for flat_max in ("48", "0"):
         monkeypatch.setenv("RTAMD_FLAT_MAX", flat_max)
         ctx = rtamd.Context(0)
+        ctx.set_tail_paths(2048)
         info = ctx.load_scene(name, seed=1)
         assert info["stack_entries"] == 1 or flat_max == "0"  # a flat scene never pushes
         cam = ctx.preset_camera(w / h)
