@@ -122,17 +122,32 @@ int rt_scene_set_perlin(rt_ctx* ctx, uint32_t table, const float* vec, const int
 /* Decoded RGB8 image, row 0 = top (texture.rs:84-93). */
 int rt_scene_set_image(rt_ctx* ctx, uint32_t table, uint32_t w, uint32_t h, const uint8_t* rgb);
 /* Stands in for BVHNode::from_scene(&world, t0, t1) (bvh_node.rs:48-120, main.rs:458): builds the
- * linear two-level BVH on the host and uploads everything. */
+ * linear two-level BVH and uploads everything.  Instances' own trees are built on the host; the world-level
+ * tree is built on the host (binned SAH) or, for large worlds, on the device (Morton-sorted linear BVH). */
 int rt_scene_commit(rt_ctx* ctx, float shutter_t0, float shutter_t1);
+/* Builder of the world-level tree at the next rt_scene_commit: -1 = by size (default: device from 262144 world
+ * primitives on, env RTAMD_GPU_BUILD_MIN), 0 = host, 1 = device (env RTAMD_BUILDER).  Every valid tree gives
+ * the same hits; the builders differ in build time and in node visits per ray. */
+int rt_ctx_set_builder(rt_ctx* ctx, int builder);
 
 typedef struct rt_scene_info {
     uint64_t n_prims, n_nodes, n_groups, n_media;
     uint32_t max_depth;    /* deepest stack the traversal can need */
     uint32_t stack_entries; /* traversal stack entries per lane the kernels are launched with (1 for flat scenes) */
     uint64_t device_bytes;
-    double build_seconds;
+    double build_seconds;  /* all of rt_scene_commit */
+    double tree_seconds;   /* of which: the world-level tree (build + upload of nodes and primitives) */
+    uint32_t builder;      /* 0 host, 1 device */
+    uint32_t reserved;
 } rt_scene_info;
 int rt_scene_get_info(rt_ctx* ctx, rt_scene_info* out);
+/* Inspection (tests, tools): copies the committed tree to host memory.  nodes: n_nodes records of 64 bytes
+ * {float lo0[3], hi0[3], lo1[3], hi1[3]; uint32 c0, c1, pad[2]} (both child boxes, two child references);
+ * prims: n_prims records of 32 bytes {float a[4], b0; uint32 info, id, aux} in leaf order.  A reference has
+ * its type in bits 31..30 (0 inner node, 1 primitive range: bits 29..26 = count-1, bits 25..0 = first,
+ * 2 instance group); 0xFFFFFFFF = empty.  Either pointer may be NULL. */
+int rt_scene_read_bvh(rt_ctx* ctx, void* nodes, uint64_t nodes_bytes, void* prims, uint64_t prims_bytes,
+                      uint32_t* root_ref);
 
 /* ---- camera (camera.rs:14-25; built by Camera::new, camera.rs:28-52) ------ */
 typedef struct rt_camera {

@@ -16,6 +16,7 @@
 #include "rt_bvh.h"
 #include "rt_device.h"
 #include "rt_kernels.h"
+#include "rt_lbvh.h"
 
 namespace {
 
@@ -82,6 +83,8 @@ struct rt_ctx {
     int pipeline = -1;  // -1 choose per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce), 2 hybrid
     int deep_pipeline = 2;  // what trees above fused_node_limit take
     uint64_t fused_node_limit = 64;  // scenes with more BVH nodes than this take deep_pipeline
+    int builder = -1;  // world-level BVH: -1 by size, 0 host (binned SAH), 1 device (linear BVH)
+    uint64_t gpu_build_min = 1u << 18;  // builder -1: worlds with at least this many primitives are built on the device
     uint64_t tail_paths = 256u << 10;  // a batch with at most this many live paths is finished by one k_finish launch
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
@@ -329,6 +332,8 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (getenv("RTAMD_DEEP_PIPELINE")) c->deep_pipeline = (int)std::min(env_u32("RTAMD_DEEP_PIPELINE", 2), 2u);
     if (getenv("RTAMD_FUSED_NODE_LIMIT")) c->fused_node_limit = env_u32("RTAMD_FUSED_NODE_LIMIT", 0);
     if (getenv("RTAMD_TAIL_PATHS")) c->tail_paths = env_u32("RTAMD_TAIL_PATHS", 0);
+    if (getenv("RTAMD_BUILDER")) c->builder = (int)std::min(env_u32("RTAMD_BUILDER", 0), 1u);
+    if (getenv("RTAMD_GPU_BUILD_MIN")) c->gpu_build_min = env_u32("RTAMD_GPU_BUILD_MIN", 0);
     *out = c;
     return RT_OK;
 }
@@ -366,6 +371,11 @@ int rt_ctx_set_max_paths(rt_ctx* c, uint64_t max_paths) {
 int rt_ctx_set_pipeline(rt_ctx* c, int pipeline) {
     if (!c || pipeline < -1 || pipeline > 2) return fail(c, RT_ERR_INVALID, "pipeline must be -1, 0, 1 or 2");
     c->pipeline = pipeline;
+    return RT_OK;
+}
+int rt_ctx_set_builder(rt_ctx* c, int builder) {
+    if (!c || builder < -1 || builder > 1) return fail(c, RT_ERR_INVALID, "builder must be -1, 0 or 1");
+    c->builder = builder;
     return RT_OK;
 }
 int rt_ctx_set_tail_paths(rt_ctx* c, uint64_t tail_paths) {
@@ -607,28 +617,146 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     // top level: world primitives + groups
     const auto& world = members[0];
     const size_t n_group_items = top.size();
-    top.resize(n_group_items + world.size());
-    for (size_t i = 0; i < world.size(); i++) {
-        rtb::Item& it = top[n_group_items + i];
-        prim_box(world[i], it.lo, it.hi);
-        it.payload = (uint32_t)i;
-        it.type = rtd::REF_PRIMS;
-    }
-    std::vector<uint32_t> order;
     const uint32_t base = (uint32_t)prims.size();
-    rtb::Result top_r = rtb::build(top, leaf_max, false, base, nodes, order);
-    for (uint32_t oi : order) prims.push_back(make_prim(c, world[oi], moving));
+    // Large worlds are built on the device (rt_lbvh.h); a flat scene has no tree, and a world of one primitive
+    // has no inner node.
+    const bool device_build = !flat_ok && world.size() >= 2 &&
+                              (c->builder == 1 || (c->builder < 0 && world.size() >= c->gpu_build_min));
+    auto ttree = std::chrono::steady_clock::now();
+    rtb::Result top_r;
+    uint32_t lbvh_depth = 0;
+    uint64_t n_nodes_total = 0;
+    int rc;
+    if (!device_build) {
+        top.resize(n_group_items + world.size());
+        for (size_t i = 0; i < world.size(); i++) {
+            rtb::Item& it = top[n_group_items + i];
+            prim_box(world[i], it.lo, it.hi);
+            it.payload = (uint32_t)i;
+            it.type = rtd::REF_PRIMS;
+        }
+        std::vector<uint32_t> order;
+        top_r = rtb::build(top, leaf_max, false, base, nodes, order);
+        for (uint32_t oi : order) prims.push_back(make_prim(c, world[oi], moving));
+        if ((rc = upload(c, c->d_prims, prims.data(), prims.size() * sizeof(rtd::Prim)))) return rc;
+        if ((rc = upload(c, c->d_moving, moving.data(), moving.size() * sizeof(rtd::Moving)))) return rc;
+        if ((rc = upload(c, c->d_nodes, nodes.data(), nodes.size() * sizeof(rtd::Node)))) return rc;
+        n_nodes_total = nodes.size();
+    } else {
+        // A linear BVH sorts by box centre only, so one huge primitive (a ground sphere) would inflate every
+        // box on its path to the root.  Primitives whose box is large against the spread of the centres are
+        // therefore kept out of the sort and sit in the small host-built top level next to the instances.
+        const uint32_t nw_all = (uint32_t)world.size();
+        std::vector<float> side(nw_all);
+        float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < nw_all; i++) {
+            float ctr[3];
+            if (world[i].sphere) {
+                const float* a = &c->sph.c0r[4 * (size_t)world[i].idx];
+                for (int k = 0; k < 3; k++) ctr[k] = a[k];
+                side[i] = 2.0f * std::fabs(a[3]);
+            } else {
+                float lo[3], hi[3];
+                rect_box(c, world[i].idx, lo, hi);
+                side[i] = 0.0f;
+                for (int k = 0; k < 3; k++) {
+                    ctr[k] = 0.5f * (lo[k] + hi[k]);
+                    side[i] = std::max(side[i], hi[k] - lo[k]);
+                }
+            }
+            for (int k = 0; k < 3; k++) {
+                cmin[k] = std::min(cmin[k], ctr[k]);
+                cmax[k] = std::max(cmax[k], ctr[k]);
+            }
+        }
+        const float spread = std::max(std::max(cmax[0] - cmin[0], cmax[1] - cmin[1]), cmax[2] - cmin[2]);
+        std::vector<uint32_t> large;
+        for (uint32_t i = 0; i < nw_all; i++)
+            if (side[i] > 0.125f * spread) large.push_back(i);
+        if (large.size() > 4096 || nw_all - large.size() < 2) large.clear();  // no few-big / many-small structure: sort everything
+        std::vector<uint8_t> is_large(nw_all, 0);
+        for (uint32_t i : large) is_large[i] = 1;
+        const uint32_t nw = nw_all - (uint32_t)large.size();
+        std::vector<rtd::Prim> wprims;
+        wprims.reserve(nw);
+        for (uint32_t i = 0; i < nw_all; i++)
+            if (!is_large[i]) wprims.push_back(make_prim(c, world[i], moving));
+        // moving[] grows while the large primitives' records are made too; they are made now so that one upload holds all
+        std::vector<rtd::Prim> large_prims(large.size());
+        for (size_t k = 0; k < large.size(); k++) {
+            large_prims[k] = make_prim(c, world[large[k]], moving);
+            rtb::Item it;
+            prim_box(world[large[k]], it.lo, it.hi);
+            it.payload = (uint32_t)k;
+            it.type = rtd::REF_PRIMS;
+            top.push_back(it);
+        }
+        if ((rc = upload(c, c->d_moving, moving.data(), moving.size() * sizeof(rtd::Moving)))) return rc;
+        if ((rc = ensure(c, c->d_prims, ((size_t)base + nw_all) * sizeof(rtd::Prim)))) return rc;
+        if (base) HIP_TRY(c, hipMemcpy(c->d_prims.p, prims.data(), (size_t)base * sizeof(rtd::Prim), hipMemcpyHostToDevice));
+        DevBuf unsorted;
+        if ((rc = upload(c, unsorted, wprims.data(), (size_t)nw * sizeof(rtd::Prim)))) return rc;
+        rtl::Workspace ws;
+        float wlo[3], whi[3];
+        hipError_t e = rtl::sort_world(c->stream, ws, (const rtd::Prim*)unsorted.p, (const rtd::Moving*)c->d_moving.p, nw, shutter_t0,
+                                       shutter_t1, (rtd::Prim*)c->d_prims.p + base, wlo, whi);
+        unsorted.release();
+        uint32_t node_base = (uint32_t)nodes.size();
+        if (e == hipSuccess && !top.empty()) {
+            // instances and large primitives share the top level with the world: a small host tree over them and one
+            // item that stands for the whole device-built tree (its reference is patched in once the node index is known)
+            constexpr uint32_t PLACEHOLDER = 0x3FFFFFFDu;
+            rtb::Item it;
+            memcpy(it.lo, wlo, sizeof(wlo));
+            memcpy(it.hi, whi, sizeof(whi));
+            it.payload = PLACEHOLDER;
+            it.type = rtd::REF_INNER;
+            top.push_back(it);
+            std::vector<uint32_t> order;
+            top_r = rtb::build(top, leaf_max, false, base + nw, nodes, order);
+            if (!order.empty()) {
+                std::vector<rtd::Prim> in_leaf_order(order.size());
+                for (size_t k = 0; k < order.size(); k++) in_leaf_order[k] = large_prims[order[k]];
+                e = hipMemcpy((rtd::Prim*)c->d_prims.p + base + nw, in_leaf_order.data(), order.size() * sizeof(rtd::Prim), hipMemcpyHostToDevice);
+            }
+            node_base = (uint32_t)nodes.size();
+            const uint32_t from = rtd::make_ref(rtd::REF_INNER, PLACEHOLDER), to = rtd::make_ref(rtd::REF_INNER, node_base);
+            for (rtd::Node& nd : nodes) {
+                if (nd.c0 == from) nd.c0 = to;
+                if (nd.c1 == from) nd.c1 = to;
+            }
+            if (top_r.root_ref == from) top_r.root_ref = to;
+        } else {
+            top_r.root_ref = rtd::make_ref(rtd::REF_INNER, node_base);
+            top_r.depth = 0;
+        }
+        n_nodes_total = (uint64_t)node_base + nw - 1;
+        if (e == hipSuccess && n_nodes_total >= (1ull << 30)) {
+            ws.release();
+            return fail(c, RT_ERR_UNSUPPORTED, "more than 2^30 BVH nodes");
+        }
+        if (e == hipSuccess) {
+            if ((rc = ensure(c, c->d_nodes, n_nodes_total * sizeof(rtd::Node)))) {
+                ws.release();
+                return rc;
+            }
+            if (node_base) e = hipMemcpy(c->d_nodes.p, nodes.data(), (size_t)node_base * sizeof(rtd::Node), hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess)
+            e = rtl::build_tree(c->stream, ws, (const rtd::Prim*)c->d_prims.p + base, (const rtd::Moving*)c->d_moving.p, nw, shutter_t0,
+                                shutter_t1, base, (rtd::Node*)c->d_nodes.p + node_base, node_base, &lbvh_depth);
+        ws.release();
+        if (e != hipSuccess) return hip_fail(c, e, "device BVH build");
+    }
+    c->info.tree_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - ttree).count();
+    const uint64_t n_prims_total = device_build ? (uint64_t)base + world.size() : prims.size();
 
-    uint32_t need = top_r.depth + (n_inst ? 1 + blas_depth : 0) + 1;
+    uint32_t need = top_r.depth + lbvh_depth + (n_inst ? 1 + blas_depth : 0) + 1;
     if (need > 64) return fail(c, RT_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack");
     c->stack_entries = (int)(flat_ok ? 1u : need);
     c->has_groups = ng > 0;
 
     // upload
-    int rc;
-    if ((rc = upload(c, c->d_prims, prims.data(), prims.size() * sizeof(rtd::Prim)))) return rc;
-    if ((rc = upload(c, c->d_moving, moving.data(), moving.size() * sizeof(rtd::Moving)))) return rc;
-    if ((rc = upload(c, c->d_nodes, nodes.data(), nodes.size() * sizeof(rtd::Node)))) return rc;
     if ((rc = upload(c, c->d_groups, dgroups.data(), dgroups.size() * sizeof(rtd::Group)))) return rc;
     if ((rc = upload(c, c->d_media, media_groups.data(), media_groups.size() * sizeof(uint32_t)))) return rc;
     static_assert(sizeof(rt_material) == sizeof(rtd::Material), "material layout");
@@ -701,7 +829,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.images = (const rtd::Image*)c->d_images.p;
     S.media = (const uint32_t*)c->d_media.p;
     S.root_ref = top_r.root_ref;
-    S.n_prims = (uint32_t)prims.size();
+    S.n_prims = (uint32_t)n_prims_total;
     S.n_groups = ng;
     S.n_media = n_media;
     S.flat = flat_ok ? 1u : 0u;
@@ -709,14 +837,15 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.world_first = base;
     S.world_count = (uint32_t)world.size();
 
-    c->info.n_prims = prims.size();
-    c->info.n_nodes = nodes.size();
+    c->info.n_prims = n_prims_total;
+    c->info.n_nodes = n_nodes_total;
+    c->info.builder = device_build ? 1u : 0u;
     c->info.n_groups = ng;
     c->info.n_media = n_media;
     c->info.max_depth = need;
     c->info.stack_entries = (uint32_t)c->stack_entries;
-    c->info.device_bytes = prims.size() * sizeof(rtd::Prim) + moving.size() * sizeof(rtd::Moving) +
-                           nodes.size() * sizeof(rtd::Node) + dgroups.size() * sizeof(rtd::Group) +
+    c->info.device_bytes = n_prims_total * sizeof(rtd::Prim) + moving.size() * sizeof(rtd::Moving) +
+                           n_nodes_total * sizeof(rtd::Node) + dgroups.size() * sizeof(rtd::Group) +
                            c->mats.size() * sizeof(rt_material) + c->texs.size() * sizeof(rt_texture) +
                            ptab.size() * sizeof(rtd::PerlinTable) + image_bytes;
     c->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
@@ -728,6 +857,19 @@ int rt_scene_get_info(rt_ctx* c, rt_scene_info* out) {
     if (!c || !out) return RT_ERR_INVALID;
     if (!c->committed) return fail(c, RT_ERR_NOT_COMMITTED, "scene not committed");
     *out = c->info;
+    return RT_OK;
+}
+
+int rt_scene_read_bvh(rt_ctx* c, void* nodes, uint64_t nodes_bytes, void* prims, uint64_t prims_bytes, uint32_t* root_ref) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->committed) return fail(c, RT_ERR_NOT_COMMITTED, "rt_scene_read_bvh before rt_scene_commit");
+    if (nodes_bytes < c->info.n_nodes * sizeof(rtd::Node) || prims_bytes < c->info.n_prims * sizeof(rtd::Prim))
+        return fail(c, RT_ERR_INVALID, "rt_scene_read_bvh: buffer too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (nodes && c->info.n_nodes) HIP_TRY(c, hipMemcpy(nodes, c->d_nodes.p, c->info.n_nodes * sizeof(rtd::Node), hipMemcpyDeviceToHost));
+    if (prims && c->info.n_prims) HIP_TRY(c, hipMemcpy(prims, c->d_prims.p, c->info.n_prims * sizeof(rtd::Prim), hipMemcpyDeviceToHost));
+    if (root_ref) *root_ref = c->scene.root_ref;
     return RT_OK;
 }
 

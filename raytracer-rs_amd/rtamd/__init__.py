@@ -29,7 +29,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPP
 # every symbol include/rtamd.h declares
 ABI_SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_ctx_set_stream", "rt_ctx_set_max_paths",
-    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
+    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_set_builder", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
     "rt_resolve_u8", "rt_owned_pixels")
@@ -71,7 +71,8 @@ class rt_render_stats(C.Structure):
 class rt_scene_info(C.Structure):
     _fields_ = [("n_prims", C.c_uint64), ("n_nodes", C.c_uint64), ("n_groups", C.c_uint64), ("n_media", C.c_uint64),
                 ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32), ("device_bytes", C.c_uint64),
-                ("build_seconds", C.c_double)]
+                ("build_seconds", C.c_double), ("tree_seconds", C.c_double), ("builder", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -120,6 +121,8 @@ def core():
     L.rt_ctx_synchronize.argtypes = [vp]
     L.rt_ctx_set_pipeline.argtypes = [vp, C.c_int]
     L.rt_ctx_set_tail_paths.argtypes = [vp, u64]
+    L.rt_ctx_set_builder.argtypes = [vp, C.c_int]
+    L.rt_scene_read_bvh.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u32)]
     L.rt_scene_clear.argtypes = [vp]
     L.rt_scene_set_spheres.argtypes = [vp, u32] + [vp] * 7
     L.rt_scene_set_rects.argtypes = [vp, u32] + [vp] * 6
@@ -273,6 +276,22 @@ class Context:
     def set_pipeline(self, pipeline):
         """-1 pick per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce)."""
         self._check(self.L.rt_ctx_set_pipeline(self.h, pipeline))
+
+    def set_builder(self, builder):
+        """World-level BVH builder of the next commit: -1 by size, 0 host (binned SAH), 1 device (linear BVH)."""
+        self._check(self.L.rt_ctx_set_builder(self.h, builder))
+
+    def read_bvh(self):
+        """(nodes, prims, root_ref): the committed tree as numpy structured arrays (see rt_scene_read_bvh)."""
+        info = self.info()
+        node_t = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("c0", "<u4"),
+                           ("c1", "<u4"), ("pad", "<u4", 2)])
+        prim_t = np.dtype([("a", "<f4", 4), ("b0", "<f4"), ("info", "<u4"), ("id", "<u4"), ("aux", "<u4")])
+        nodes = np.zeros(info["n_nodes"], node_t)
+        prims = np.zeros(info["n_prims"], prim_t)
+        root = C.c_uint32(0)
+        self._check(self.L.rt_scene_read_bvh(self.h, nodes.ctypes.data, nodes.nbytes, prims.ctypes.data, prims.nbytes, C.byref(root)))
+        return nodes, prims, root.value
 
     def set_tail_paths(self, n):
         """Live-path count at or below which one launch finishes a batch (0 = one launch per bounce to the end)."""
