@@ -29,7 +29,8 @@ typedef enum rt_status {
     RT_ERR_HIP = -2,           /* a HIP runtime call failed */
     RT_ERR_UNSUPPORTED = -3,   /* scene shape the device path does not handle */
     RT_ERR_NOT_COMMITTED = -4, /* work call before rt_scene_commit */
-    RT_ERR_NO_DEVICE = -5      /* no usable GPU */
+    RT_ERR_NO_DEVICE = -5,     /* no usable GPU */
+    RT_ERR_IO = -6             /* a file could not be written or read */
 } rt_status;
 
 /* ---- context ----------------------------------------------------------- */
@@ -216,6 +217,26 @@ int rt_profile_enable(rt_ctx* ctx, int flags);
 /* vec3_to_rgb(color * inv_samples) (main.rs:307-313,460,481): out[i] = (256*clamp(sum[i]/spp,0,0.999)) as u8.
  * sum_rgb and out: host or device. */
 int rt_resolve_u8(rt_ctx* ctx, const float* sum_rgb, uint64_t n_pixels, uint32_t spp, uint8_t* out);
+
+/* The same with a transfer curve: RT_TRANSFER_LINEAR is rt_resolve_u8 (what main.rs:307-313 does);
+ * RT_TRANSFER_SQRT takes the square root of the mean first -- the gamma-2 write_color the reference keeps
+ * commented out (main.rs:35-42): (256*clamp(sqrt(sum[i]/spp),0,0.999)) as u8. */
+typedef enum rt_transfer { RT_TRANSFER_LINEAR = 0, RT_TRANSFER_SQRT = 1 } rt_transfer;
+int rt_resolve_u8_transfer(rt_ctx* ctx, const float* sum_rgb, uint64_t n_pixels, uint32_t spp, int transfer, uint8_t* out);
+
+/* ---- output files (host only; no GPU needed) -----------------------------------------
+ * Stands in for main.rs:486-497 (interleave + image::save("./test.png")): writes height x width x 3 bytes,
+ * row 0 = top, as an 8-bit RGB PNG or a binary PPM (P6). */
+typedef enum rt_image_format { RT_IMAGE_PNG = 0, RT_IMAGE_PPM = 1 } rt_image_format;
+int rt_image_write(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb, int format);
+/* Checkpoint of a progressive render (the reference has none; its render is all-or-nothing): the f32 sample
+ * sums (host, height x width x 3) together with the number of samples they hold and the seed.  Continue with
+ * rt_render(sample0 = samples_done, ...) into the loaded buffer: the result equals the uninterrupted render
+ * bit for bit.  rt_accum_read with accum_rgb == NULL only reads the header. */
+int rt_accum_write(const char* path, uint32_t width, uint32_t height, uint32_t samples_done, uint32_t seed,
+                   const float* accum_rgb);
+int rt_accum_read(const char* path, uint32_t* width, uint32_t* height, uint32_t* samples_done, uint32_t* seed,
+                  float* accum_rgb, uint64_t cap_floats);
 
 /* Pixels owned by `rank` under the tile deal of rt_render, in render order (tile-major). Writes up to
  * cap pixel indices (y*width+x) to out (host) and returns the count in *n. */

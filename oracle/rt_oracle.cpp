@@ -1514,6 +1514,12 @@ void orc_resolve_u8(const float* sum_rgb, int64_t n_pixels, int spp, uint8_t* ou
     for (int64_t i = 0; i < n_pixels * 3; i++) out[i] = float_to_u8_color(sum_rgb[i] * inv);
 }
 
+// the write_color the reference keeps commented out (main.rs:35-42): square root of the mean, then the same quantisation
+void orc_resolve_u8_sqrt(const float* sum_rgb, int64_t n_pixels, int spp, uint8_t* out) {
+    float inv = 1.0f / (float)spp;
+    for (int64_t i = 0; i < n_pixels * 3; i++) out[i] = float_to_u8_color(std::sqrt(sum_rgb[i] * inv));
+}
+
 void orc_rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first, int n, uint32_t* out) {
     Stream s = path_stream(seed, pixel, sample);
     s.n = first;

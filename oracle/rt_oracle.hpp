@@ -86,6 +86,7 @@ int orc_render(const orc_scene*, int mode, int w, int h, float aspect,
                float* sum_rgb, uint64_t* rays_out, uint64_t* counters, int threads);
 // vec3_to_rgb(color * inv_samples) (src/main.rs:307-313,460,481)
 void orc_resolve_u8(const float* sum_rgb, int64_t n_pixels, int spp, uint8_t* out);
+void orc_resolve_u8_sqrt(const float* sum_rgb, int64_t n_pixels, int spp, uint8_t* out);
 
 // ---- RNG specification probes ---------------------------------------------
 void orc_rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t first, int n, uint32_t* out);

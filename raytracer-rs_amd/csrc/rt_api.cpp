@@ -1160,7 +1160,12 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
 }
 
 int rt_resolve_u8(rt_ctx* c, const float* sum_rgb, uint64_t n_pixels, uint32_t spp, uint8_t* out) {
+    return rt_resolve_u8_transfer(c, sum_rgb, n_pixels, spp, RT_TRANSFER_LINEAR, out);
+}
+
+int rt_resolve_u8_transfer(rt_ctx* c, const float* sum_rgb, uint64_t n_pixels, uint32_t spp, int transfer, uint8_t* out) {
     if (!c || !sum_rgb || !out || !spp) return fail(c, RT_ERR_INVALID, "rt_resolve_u8: bad argument");
+    if (transfer != RT_TRANSFER_LINEAR && transfer != RT_TRANSFER_SQRT) return fail(c, RT_ERR_INVALID, "rt_resolve_u8: unknown transfer");
     if (n_pixels == 0) return RT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t n = n_pixels * 3;
@@ -1182,7 +1187,7 @@ int rt_resolve_u8(rt_ctx* c, const float* sum_rgb, uint64_t n_pixels, uint32_t s
         }
         d_out = (uint8_t*)dout.p;
     }
-    if (e == hipSuccess) e = rtk::launch_resolve(c->stream, d_in, n, spp, d_out);
+    if (e == hipSuccess) e = rtk::launch_resolve(c->stream, d_in, n, spp, transfer == RT_TRANSFER_SQRT, d_out);
     if (!out_dev && e == hipSuccess) e = hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream);
     hipError_t e2 = hipStreamSynchronize(c->stream);
     din.release();

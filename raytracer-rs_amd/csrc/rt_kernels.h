@@ -72,7 +72,7 @@ hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& s
                          uint32_t* overflow_flag);
 
 hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, uint32_t width, float* accum_rgb);
-hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, uint8_t* out);
+hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, bool sqrt_transfer, uint8_t* out);
 hipError_t launch_intersect_batch(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, uint64_t n,
                                   const float* const rays[7], float tmin, float tmax, uint32_t seed, int32_t* prim,
                                   int32_t* inst, float* t, float* normal, uint8_t* front, float* uv, float* point,

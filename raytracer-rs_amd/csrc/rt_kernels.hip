@@ -427,11 +427,13 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restr
     }
 }
 
+template <bool SQRT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_resolve(const float* __restrict__ sum_rgb, unsigned long long n, float inv,
                                                          uint8_t* __restrict__ out) {
     for (unsigned long long i = (unsigned long long)blockIdx.x * rtk::BLOCK + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * rtk::BLOCK) {
         float f = sum_rgb[i] * inv;                      // main.rs:481
+        if (SQRT) f = __builtin_sqrtf(f);                // main.rs:37-39 (commented-out write_color)
         float x = 256.0f * rust_clamp(f, 0.0f, 0.999f);  // main.rs:307-309
         uint32_t qv = rust_as_u32(x);
         out[i] = (uint8_t)(qv > 255u ? 255u : qv);
@@ -632,9 +634,12 @@ hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch&
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, uint8_t* out) {
+hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, bool sqrt_transfer, uint8_t* out) {
     float inv = 1.0f / (float)spp;  // main.rs:460
-    hipLaunchKernelGGL(k_resolve, dim3(grid_flat(n_values)), dim3(BLOCK), 0, s, sum_rgb, (unsigned long long)n_values, inv, out);
+    if (sqrt_transfer)
+        hipLaunchKernelGGL(k_resolve<true>, dim3(grid_flat(n_values)), dim3(BLOCK), 0, s, sum_rgb, (unsigned long long)n_values, inv, out);
+    else
+        hipLaunchKernelGGL(k_resolve<false>, dim3(grid_flat(n_values)), dim3(BLOCK), 0, s, sum_rgb, (unsigned long long)n_values, inv, out);
     return hipGetLastError();
 }
 

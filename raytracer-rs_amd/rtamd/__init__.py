@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_set_builder", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
-    "rt_resolve_u8", "rt_owned_pixels")
+    "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_accum_write", "rt_accum_read", "rt_owned_pixels")
 
 
 class RtError(RuntimeError):
@@ -137,6 +137,10 @@ def core():
     L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, C.POINTER(rt_render_stats)]
     L.rt_profile_enable.argtypes = [vp, C.c_int]
     L.rt_resolve_u8.argtypes = [vp, vp, u64, u32, vp]
+    L.rt_resolve_u8_transfer.argtypes = [vp, vp, u64, u32, C.c_int, vp]
+    L.rt_image_write.argtypes = [C.c_char_p, u32, u32, vp, C.c_int]
+    L.rt_accum_write.argtypes = [C.c_char_p, u32, u32, u32, u32, vp]
+    L.rt_accum_read.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, u64]
     L.rt_owned_pixels.argtypes = [u32, u32, u32, u32, u32, vp, u64, C.POINTER(u64)]
     for s in ABI_SYMBOLS:
         fn = getattr(L, s)
@@ -231,6 +235,40 @@ def flatten_counts(name, seed=1, n_synth=0, earthmap=None):
         return out
     finally:
         H.rth_scene_destroy(C.c_void_p(h))
+
+
+def write_image(path, rgb8, fmt="png"):
+    """(h, w, 3) uint8, row 0 = top -> PNG or binary PPM (stands in for main.rs:486-497)."""
+    a = np.ascontiguousarray(rgb8.cpu().numpy() if _is_torch(rgb8) else rgb8, dtype=np.uint8)
+    h, w, ch = a.shape
+    if ch != 3:
+        raise ValueError("write_image wants (h, w, 3)")
+    rc = core().rt_image_write(str(path).encode(), w, h, a.ctypes.data, {"png": 0, "ppm": 1}[fmt])
+    if rc:
+        raise RtError(rc, f"rt_image_write({path})")
+
+
+def save_accum(path, accum, samples_done, seed):
+    """Checkpoint of a progressive render: f32 sample sums (h, w, 3) + how many samples they hold + the seed."""
+    a = np.ascontiguousarray(accum.cpu().numpy() if _is_torch(accum) else accum, dtype=np.float32)
+    h, w, _ = a.shape
+    rc = core().rt_accum_write(str(path).encode(), w, h, samples_done, seed, a.ctypes.data)
+    if rc:
+        raise RtError(rc, f"rt_accum_write({path})")
+
+
+def load_accum(path):
+    """-> (accum (h, w, 3) float32, samples_done, seed); continue with render(..., sample0=samples_done, accum=accum)."""
+    L = core()
+    w, h, done, seed = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = L.rt_accum_read(str(path).encode(), C.byref(w), C.byref(h), C.byref(done), C.byref(seed), None, 0)
+    if rc:
+        raise RtError(rc, f"rt_accum_read({path})")
+    a = np.empty((h.value, w.value, 3), np.float32)
+    rc = L.rt_accum_read(str(path).encode(), None, None, None, None, a.ctypes.data, a.size)
+    if rc:
+        raise RtError(rc, f"rt_accum_read({path})")
+    return a, done.value, seed.value
 
 
 class Context:
@@ -434,12 +472,13 @@ class Context:
         self._check(self.L.rt_render(self.h, C.byref(cam), C.byref(p), _ptr(accum), C.byref(st)))
         return accum, st.as_dict()
 
-    def resolve_u8(self, accum, spp):
+    def resolve_u8(self, accum, spp, transfer=0):
+        """transfer 0: linear (main.rs:307-313); 1: square root first (the commented-out write_color, main.rs:35-42)."""
         if _is_torch(accum):
             import torch
             out = torch.empty(accum.shape, dtype=torch.uint8, device=accum.device)
         else:
             out = np.empty(accum.shape, dtype=np.uint8)
         n_pixels = int(np.prod(accum.shape)) // 3
-        self._check(self.L.rt_resolve_u8(self.h, _ptr(accum), n_pixels, spp, _ptr(out)))
+        self._check(self.L.rt_resolve_u8_transfer(self.h, _ptr(accum), n_pixels, spp, transfer, _ptr(out)))
         return out

@@ -46,6 +46,7 @@ def lib():
     L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_uint32,
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_resolve_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.orc_resolve_u8_sqrt.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     L.orc_rng_u32.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     L.orc_rng_f32.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
     L.orc_rng_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, c_f, c_f, C.c_int, C.c_void_p]
@@ -199,9 +200,10 @@ class Scene:
         return sum_rgb, int(rays.value)
 
 
-def resolve_u8(sum_rgb, spp):
+def resolve_u8(sum_rgb, spp, sqrt=False):
     out = np.empty(sum_rgb.shape, dtype=np.uint8)
-    lib().orc_resolve_u8(_ptr(np.ascontiguousarray(sum_rgb)), sum_rgb.size // 3, spp, _ptr(out))
+    fn = lib().orc_resolve_u8_sqrt if sqrt else lib().orc_resolve_u8
+    fn(_ptr(np.ascontiguousarray(sum_rgb)), sum_rgb.size // 3, spp, _ptr(out))
     return out
 
 

@@ -223,3 +223,36 @@ def test_tile_gather_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o[-2000:]
+
+
+# ---- output files (host only) -------------------------------------------------------------------------
+def test_image_write_png_and_ppm_round_trip(tmp_path):
+    """rt_image_write stands in for main.rs:486-497.  The PNG is read back with Pillow, the PPM by hand."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    for (h, w) in ((1, 1), (7, 13), (225, 400)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img[h // 2:, :, :] = 77  # something compressible too
+        rtamd.write_image(tmp_path / "a.png", img, "png")
+        back = np.asarray(Image.open(tmp_path / "a.png"))
+        assert back.shape == img.shape and back.dtype == np.uint8 and np.array_equal(back, img)
+        rtamd.write_image(tmp_path / "a.ppm", img, "ppm")
+        raw = (tmp_path / "a.ppm").read_bytes()
+        head = f"P6\n{w} {h}\n255\n".encode()
+        assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3), img)
+    with pytest.raises(rtamd.RtError):
+        rtamd.write_image(tmp_path / "no_such_dir" / "a.png", img, "png")
+
+
+def test_accum_checkpoint_round_trip(tmp_path):
+    rng = np.random.default_rng(2)
+    acc = rng.uniform(0, 50, (9, 17, 3)).astype(np.float32)
+    acc[0, 0] = [np.inf, 0.0, 1e-30]
+    rtamd.save_accum(tmp_path / "c.acc", acc, 37, 12345)
+    back, done, seed = rtamd.load_accum(tmp_path / "c.acc")
+    assert done == 37 and seed == 12345 and back.dtype == np.float32 and np.array_equal(back, acc)
+    (tmp_path / "bad.acc").write_bytes(b"not a checkpoint")
+    with pytest.raises(rtamd.RtError):
+        rtamd.load_accum(tmp_path / "bad.acc")
+    with pytest.raises(rtamd.RtError):
+        rtamd.load_accum(tmp_path / "missing.acc")

@@ -224,6 +224,34 @@ def test_resolve_u8_edge_values(gpu_ctx):
     assert np.array_equal(gpu_ctx.resolve_u8(big, 7), orc.resolve_u8(big, 7))
 
 
+def test_resolve_sqrt_transfer_matches_oracle(gpu_ctx):
+    """The gamma-2 write_color the reference keeps commented out (main.rs:35-42), offered as a switch."""
+    rng = np.random.default_rng(3)
+    sums = (rng.uniform(-0.1, 1.2, (50, 70, 3)) * 9).astype(np.float32)
+    sums[0, 0] = [np.nan, np.inf, 0.0]
+    assert np.array_equal(gpu_ctx.resolve_u8(sums, 9, transfer=1), orc.resolve_u8(sums, 9, sqrt=True))
+    assert np.array_equal(gpu_ctx.resolve_u8(sums, 9, transfer=0), orc.resolve_u8(sums, 9))
+    vals = np.float32([[[0.25, 1.0, 0.0]]])
+    assert gpu_ctx.resolve_u8(vals, 1, transfer=1).reshape(-1).tolist() == [128, 255, 0]
+
+
+def test_checkpointed_render_continues_bit_exactly(gpu_ctx, tmp_path):
+    """Stop after 3 samples, write the checkpoint, read it back, continue to 8: equals the uninterrupted render."""
+    name, w, h = "cornell_smoke", 96, 96
+    gpu_ctx.load_scene(name, seed=1)
+    cam = gpu_ctx.preset_camera(1.0)
+    full, _ = gpu_ctx.render(w, h, cam, 8, seed=6)
+    part, _ = gpu_ctx.render(w, h, cam, 3, seed=6)
+    rtamd.save_accum(tmp_path / "r.acc", part, 3, 6)
+    acc, done, seed = rtamd.load_accum(tmp_path / "r.acc")
+    assert (done, seed) == (3, 6)
+    gpu_ctx.render(w, h, cam, 8 - done, seed=seed, accum=acc, sample0=done)
+    assert np.array_equal(acc, full)
+    rtamd.write_image(tmp_path / "r.png", gpu_ctx.resolve_u8(acc, 8), "png")
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "r.png")), orc.resolve_u8(full, 8))
+
+
 # ---- properties that do not depend on size ---------------------------------------------------------------
 def test_rank_split_sample_split_and_batch_size_change_no_bit(gpu_ctx):
     name, w, h, spp = "final_scene", 200, 120, 6
