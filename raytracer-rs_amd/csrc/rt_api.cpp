@@ -834,6 +834,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.n_media = n_media;
     S.flat = flat_ok ? 1u : 0u;
     S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
+    S.n_perlin = env_u32("RTAMD_LDS_TABLES", 1) ? n_perlin : 0u;  // 0: noise lookups read the table from global memory
     S.world_first = base;
     S.world_count = (uint32_t)world.size();
 

@@ -590,11 +590,14 @@ DEV void make_record(const Scene& S, f3 wo, f3 wd, float time, const Hit& h, Rec
 // accurate form rather than in the reference's operation order: the eight-corner weighted sum of
 // perlin.rs:71-85 is the trilinear interpolation of the corner dot products with the Hermite weights, here
 // written as seven fused lerps.  Agreement with the reference order is at the 1e-7 level.
-DEV float perlin_corner(const PerlinTable& P, int h, float du, float dv, float dw) {
-    const float4 g = *reinterpret_cast<const float4*>(P.vec[h & 255]);
-    return __builtin_fmaf(g.z, dw, __builtin_fmaf(g.y, dv, g.x * du));
+template <class Tab>
+DEV float perlin_corner(const Tab& P, int h, float du, float dv, float dw) {
+    // (component loads: the table may live in LDS, whose address space a vector cast would drop)
+    const float gx = P.vec[h & 255][0], gy = P.vec[h & 255][1], gz = P.vec[h & 255][2];
+    return __builtin_fmaf(gz, dw, __builtin_fmaf(gy, dv, gx * du));
 }
-DEV float perlin_noise(const PerlinTable& P, f3 p) {  // perlin.rs:46-88
+template <class Tab>
+DEV float perlin_noise(const Tab& P, f3 p) {  // perlin.rs:46-88
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
@@ -623,7 +626,8 @@ DEV float perlin_noise(const PerlinTable& P, f3 p) {  // perlin.rs:46-88
     const float c1 = __builtin_fmaf(vv, c11 - c10, c10);
     return __builtin_fmaf(uu, c1 - c0, c0);
 }
-DEV float perlin_turb(const PerlinTable& P, f3 p, int depth) {  // perlin.rs:90-102
+template <class Tab>
+DEV float perlin_turb(const Tab& P, f3 p, int depth) {  // perlin.rs:90-102
     float acc = 0.0f;
     f3 temp = p;
     float weight = 1.0f;
@@ -667,7 +671,15 @@ DEV bool checker_is_odd(f3 p) {
     bool neg = sin_is_negative(x) ^ sin_is_negative(y) ^ sin_is_negative(z);
     return usable && neg;
 }
-DEV f3 tex_value(const Scene& S, uint32_t ti, float u, float v, f3 p) {
+// Perlin table 0 staged in LDS by the calling kernel (null when the scene has no noise texture).  A lattice
+// lookup is a gather of 64 different addresses per wave; through the vector L1 that is one cache line per lane
+// and clock, from LDS one bank per lane -- the 98 gathers of a seven-octave turbulence made the L1 the limit.
+typedef const __attribute__((address_space(3))) PerlinTable LdsPerlinTable;
+struct LdsTables {
+    LdsPerlinTable* perlin0;
+    bool has_perlin0;
+};
+DEV f3 tex_value(const Scene& S, const LdsTables& L, uint32_t ti, float u, float v, f3 p) {
     const float4* tp = reinterpret_cast<const float4*>(S.texs + ti);
     float4 T0 = tp[0], T1 = tp[1];
     uint32_t kind = __float_as_uint(T0.x) & 0xFFu;
@@ -679,8 +691,13 @@ DEV f3 tex_value(const Scene& S, uint32_t ti, float u, float v, f3 p) {
         kind = __float_as_uint(T0.x) & 0xFFu;
     }
     if (kind == TK_NOISE) {  // texture.rs:78-82
-        const PerlinTable& P = S.perlin[__float_as_uint(T1.w)];
-        float s = 1.0f + sin_turns(__builtin_fmaf(10.0f, perlin_turb(P, p, 7), T1.z * p.z));
+        const uint32_t table = __float_as_uint(T1.w);
+        float turb;
+        if (L.has_perlin0 && table == 0u)
+            turb = perlin_turb(*L.perlin0, p, 7);
+        else
+            turb = perlin_turb(S.perlin[table], p, 7);
+        float s = 1.0f + sin_turns(__builtin_fmaf(10.0f, turb, T1.z * p.z));
         return {0.5f * s, 0.5f * s, 0.5f * s};
     }
     if (kind == TK_IMAGE) {  // texture.rs:96-117
@@ -722,9 +739,9 @@ DEV float reflectance(float cosine, float ref_index) {  // materials.rs:109-114
 // carries its colour in the record.  The commit step folds SolidColor textures into the material record
 // (MF_SOLID: the colour sits in albedo), which saves a dependent texture fetch.  Evaluated once per hit, ahead
 // of the material switch, so that the texture code exists once in the kernel.
-DEV f3 material_color(const Scene& S, const Material& M, const Record& rec) {
+DEV f3 material_color(const Scene& S, const LdsTables& L, const Material& M, const Record& rec) {
     if ((M.pad & MF_SOLID) || M.kind == MK_METAL || M.kind == MK_DIELECTRIC) return ld3(M.albedo);
-    return tex_value(S, M.tex, rec.u, rec.v, rec.point);
+    return tex_value(S, L, M.tex, rec.u, rec.v, rec.point);
 }
 // returns true when the path continues; att and the scattered direction are set then
 DEV bool scatter(const Material& M, f3 color, f3 wd, const Record& rec, Rng& rng, f3& att, f3& dir) {

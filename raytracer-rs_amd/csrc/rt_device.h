@@ -120,6 +120,7 @@ struct Scene {
     // and each instance's flat_range in a loop that is uniform over the wave (flat != 0).
     uint32_t flat, world_first, world_count;
     uint32_t stack_cap;  // entries of the per-lane traversal stack the kernels are launched with (LDS, dynamic)
+    uint32_t n_perlin;   // Perlin tables; the shading kernels keep table 0 in LDS when there is one
 };
 
 }  // namespace rtd

@@ -101,7 +101,7 @@ DEV void store_path(const rtk::PathState& st, uint32_t idx, const PathRegs& p) {
 
 // One step of ray_color (main.rs:44-63) after the hit is known.  Returns true when the path goes on (p is
 // then the scattered ray with the updated throughput); otherwise its radiance has been written.
-DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, const Hit& h, uint32_t bounce,
+DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderConst& rc, PathRegs& p, const Hit& h, uint32_t bounce,
                     float4* __restrict__ radiance) {
     if (h.prim == HIT_NONE) {  // main.rs:60-62
         f3 L = p.T * ld3(rc.background);
@@ -122,7 +122,7 @@ DEV bool shade_path(const Scene& S, const rtk::RenderConst& rc, PathRegs& p, con
         make_record<false>(S, p.o, p.d, p.time, h, rec);
     Rng rng{p.k0, p.k1, bounce << 24};
     f3 att{1.0f, 1.0f, 1.0f}, dir{0.0f, 0.0f, 0.0f};
-    const f3 color = material_color(S, M, rec);
+    const f3 color = material_color(S, tabs, M, rec);
     if (scatter(M, color, p.d, rec, rng, att, dir)) {
         if (bounce + 1u >= rc.max_depth) {  // main.rs:45-47: the next ray_color call returns zero
             radiance[p.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -166,6 +166,19 @@ DEV void compact_store(CompactLds& lds, uint32_t parity, bool alive, const PathR
     }
 }
 
+// Copies Perlin table 0 into the block's dynamic LDS behind the traversal stacks (the launchers size the
+// allocation for it when the scene has a noise texture).  Must be reached by every thread of the block.
+DEV LdsTables stage_tables(const Scene& S, uint32_t* dyn_lds) {
+    uint32_t* dst = dyn_lds + S.stack_cap * rtk::BLOCK;
+    LdsTables L{(LdsPerlinTable*)dst, S.n_perlin != 0u};
+    if (S.n_perlin) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(S.perlin);
+        for (uint32_t i = threadIdx.x; i < sizeof(PerlinTable) / 4u; i += rtk::BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
+    return L;
+}
+
 // slots of a batch of n paths that fall into shard s (tiles of BLOCK slots are dealt round-robin)
 DEV uint32_t primary_count(uint32_t n, uint32_t s) {
     uint32_t tiles = (n + rtk::BLOCK - 1) / rtk::BLOCK;
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
                                                         rtk::PathState out, rtk::Queues q, uint32_t bounce,
                                                         float4* __restrict__ radiance, unsigned long long* stats,
                                                         uint32_t* overflow_flag) {
-    extern __shared__ uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
     __shared__ CompactLds clds;
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n_batch = batch.npix * batch.n_samples;
@@ -199,6 +212,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
         if (n) atomicAdd(stats, (unsigned long long)n);
     }
     uint32_t* stk = stack + threadIdx.x;
+    const LdsTables L = stage_tables(S, stack);
     TraceCount tc{0u, 0u};
     uint32_t parity = 0;
     // instrumented build only: wave cycles spent per section (s_memtime ticks), and wave tiles
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
                 cyc[1] += t1 - t0;
                 t0 = t1;
             }
-            alive = shade_path(S, rc, p, h, bounce, radiance);
+            alive = shade_path(S, L, rc, p, h, bounce, radiance);
             if (COUNT) {
                 asm volatile("" ::"v"(p.o.x), "v"(p.d.x), "v"(p.T.x));
                 t1 = __builtin_amdgcn_s_memtime();
@@ -276,7 +290,7 @@ template <bool GROUPS, bool COUNT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
                                                        uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS) {
-    extern __shared__ uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     const uint32_t shard_base = shard * q.cap_shard;
@@ -354,7 +368,11 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
                                                        const float4* __restrict__ hits, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ radiance) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // no traversal here: only the staged tables (launched with stack_cap = 0 in mind)
     __shared__ CompactLds clds;
+    Scene St = S;
+    St.stack_cap = 0;
+    const LdsTables L = stage_tables(St, stack);
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
@@ -373,7 +391,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             h.grp = __float_as_int(hv.z);
             h.key = 0;
             if (S.n_media) apply_media<false>(S, p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h, nullptr);
-            alive = shade_path(S, rc, p, h, bounce, radiance);
+            alive = shade_path(S, L, rc, p, h, bounce, radiance);
         }
         compact_store(clds, parity, alive, p, out, out_count, shard_base);
     }
@@ -387,11 +405,12 @@ template <bool GROUPS>
 __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::Queues q,
                                                         uint32_t bounce, float4* __restrict__ radiance,
                                                         unsigned long long* stats, uint32_t* overflow_flag) {
-    extern __shared__ uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     const uint32_t shard_base = shard * q.cap_shard;
     uint32_t* stk = stack + threadIdx.x;
+    const LdsTables L = stage_tables(S, stack);
     uint32_t rays = 0;
     for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
         PathRegs p;
@@ -400,7 +419,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
             Hit h;
             trace_ray<rtk::BLOCK, GROUPS, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, b, h, stk, overflow_flag, nullptr);
             rays++;
-            if (!shade_path(S, rc, p, h, b, radiance)) break;
+            if (!shade_path(S, L, rc, p, h, b, radiance)) break;
         }
     }
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
                                                                  float tmin, float tmax, uint32_t seed, int32_t* prim,
                                                                  int32_t* inst, float* t, float* normal, uint8_t* front,
                                                                  float* uv, float* point, uint32_t* overflow_flag) {
-    extern __shared__ uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
     uint32_t* stk = stack + threadIdx.x;
     for (unsigned long long i = (unsigned long long)blockIdx.x * rtk::BLOCK + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * rtk::BLOCK) {
@@ -563,6 +582,8 @@ namespace rtk {
 
 // LDS bytes of the per-lane traversal stacks of one block
 inline size_t stack_bytes(const Scene& scene) { return (size_t)std::max(1u, scene.stack_cap) * BLOCK * sizeof(uint32_t); }
+// LDS bytes of the tables a shading kernel stages (stage_tables)
+inline size_t table_bytes(const Scene& scene) { return scene.n_perlin ? sizeof(PerlinTable) : 0; }
 
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q) {
     unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
@@ -587,8 +608,9 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
 
 hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc, PathState in, PathState out,
                         const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance) {
-    hipLaunchKernelGGL(k_shade, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade, oversubscription())), dim3(BLOCK), 0, s, scene, rc, in,
-                       out, hits, q, bounce, radiance);
+    const size_t smem = table_bytes(scene);
+    hipLaunchKernelGGL(k_shade, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade, oversubscription(), smem)), dim3(BLOCK), smem, s,
+                       scene, rc, in, out, hits, q, bounce, radiance);
     return hipGetLastError();
 }
 
@@ -596,7 +618,7 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
                          PathState in, PathState out, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
                          unsigned long long* stats, uint32_t* overflow_flag) {
     const dim3 block(BLOCK);
-    const size_t smem = stack_bytes(scene);
+    const size_t smem = stack_bytes(scene) + table_bytes(scene);
     if (bounce == 0) {
 #define RT_CALL(G, C)                                                                                                     \
     hipLaunchKernelGGL((k_bounce<G, C, true>),                                                                            \
@@ -618,7 +640,7 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
 hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, PathState in, Queues q,
                          uint32_t bounce, uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
                          uint32_t* overflow_flag) {
-    const size_t smem = stack_bytes(scene);
+    const size_t smem = stack_bytes(scene) + table_bytes(scene);
     if (blocks_per_shard < 1) blocks_per_shard = 1;
     if (blocks_per_shard > (uint32_t)MAX_BLOCKS_PER_SHARD) blocks_per_shard = MAX_BLOCKS_PER_SHARD;
     const dim3 grid(blocks_per_shard * NSHARD), block(BLOCK);
