@@ -835,6 +835,10 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.flat = flat_ok ? 1u : 0u;
     S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
     S.n_perlin = env_u32("RTAMD_LDS_TABLES", 1) ? n_perlin : 0u;  // 0: noise lookups read the table from global memory
+    S.n_mats = (uint32_t)c->mats.size();
+    S.n_texs = (uint32_t)c->texs.size();
+    // small (flat) scenes: primitive, material and texture records follow the Perlin table into LDS (at most 8 KiB)
+    S.lds_scene = (flat_ok && env_u32("RTAMD_LDS_TABLES", 1) && 32ull * (n_prims_total + S.n_mats + S.n_texs) <= 8192ull) ? 1u : 0u;
     S.world_first = base;
     S.world_count = (uint32_t)world.size();
 

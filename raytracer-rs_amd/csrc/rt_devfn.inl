@@ -67,6 +67,36 @@ DEV f3 xf_vector(const float* m, f3 v) {
             (m[8] * v.x + m[9] * v.y) + m[10] * v.z};
 }
 
+// ---- tables the shading kernels stage in LDS ------------------------------------------------------------
+// Shading looks its records up with a different index in every lane: hit primitive -> material -> texture ->
+// checker child, each fetch depending on the one before, and a Perlin lattice lookup is a gather of 64
+// different addresses per wave.  Through the vector L1 a gather costs one cache line per lane and clock (the 98
+// gathers of a seven-octave turbulence made the L1 the limit), and every dependent step pays an L1/L2 latency.
+// So the calling kernel copies what is small enough into LDS once per block (stage_tables): Perlin table 0
+// whenever the scene has one, and the primitive / material / texture records of small (flat) scenes.
+typedef const __attribute__((address_space(3))) PerlinTable LdsPerlinTable;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) v4f LdsFloat4;
+struct LdsTables {
+    LdsPerlinTable* perlin0;
+    bool has_perlin0;
+    LdsFloat4* prims;  // two float4 per 32-byte record, as in the global arrays
+    LdsFloat4* mats;
+    LdsFloat4* texs;
+    bool has_scene;
+};
+DEV void load_record(const LdsTables& L, LdsFloat4* lds, const void* global, uint32_t index, float4& r0, float4& r1) {
+    if (L.has_scene) {
+        const v4f a = lds[2u * index], b = lds[2u * index + 1u];
+        r0 = make_float4(a.x, a.y, a.z, a.w);
+        r1 = make_float4(b.x, b.y, b.z, b.w);
+    } else {
+        const float4* g = reinterpret_cast<const float4*>(global) + 2u * index;
+        r0 = g[0];
+        r1 = g[1];
+    }
+}
+
 // ---- counter-based RNG ------------------------------------------------------
 //   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
 //   stream (seed,pixel,sample): h=mix32(seed^0x51ED270B); k0=mix32(pixel^h);
@@ -526,7 +556,7 @@ DEV void sphere_uv(f3 p, float& u, float& v) {  // shapes.rs:19-24
     v = theta / PI_F;
 }
 template <bool WANT_UV>
-DEV void make_record(const Scene& S, f3 wo, f3 wd, float time, const Hit& h, Record& rec) {
+DEV void make_record(const Scene& S, const LdsTables& L, f3 wo, f3 wd, float time, const Hit& h, Record& rec) {
     if (h.prim & HIT_MEDIUM_BIT) {  // shapes.rs:690-697
         const Group& G = S.groups[h.prim & 0x3FFFFFFFu];
         rec.point = wo + (h.t * wd);
@@ -548,8 +578,8 @@ DEV void make_record(const Scene& S, f3 wo, f3 wd, float time, const Hit& h, Rec
             G = nullptr;
         }
     }
-    const float4* pp = reinterpret_cast<const float4*>(S.prims + h.prim);
-    float4 A = pp[0], B = pp[1];
+    float4 A, B;
+    load_record(L, L.prims, S.prims, h.prim, A, B);
     uint32_t info = __float_as_uint(B.y);
     uint32_t kind = info & 7u;
     rec.mat = info >> 8;
@@ -671,23 +701,13 @@ DEV bool checker_is_odd(f3 p) {
     bool neg = sin_is_negative(x) ^ sin_is_negative(y) ^ sin_is_negative(z);
     return usable && neg;
 }
-// Perlin table 0 staged in LDS by the calling kernel (null when the scene has no noise texture).  A lattice
-// lookup is a gather of 64 different addresses per wave; through the vector L1 that is one cache line per lane
-// and clock, from LDS one bank per lane -- the 98 gathers of a seven-octave turbulence made the L1 the limit.
-typedef const __attribute__((address_space(3))) PerlinTable LdsPerlinTable;
-struct LdsTables {
-    LdsPerlinTable* perlin0;
-    bool has_perlin0;
-};
 DEV f3 tex_value(const Scene& S, const LdsTables& L, uint32_t ti, float u, float v, f3 p) {
-    const float4* tp = reinterpret_cast<const float4*>(S.texs + ti);
-    float4 T0 = tp[0], T1 = tp[1];
+    float4 T0, T1;
+    load_record(L, L.texs, S.texs, ti, T0, T1);
     uint32_t kind = __float_as_uint(T0.x) & 0xFFu;
     for (int it = 0; it < 8 && kind == TK_CHECKER; it++) {  // texture.rs:52-62
         ti = checker_is_odd(p) ? __float_as_uint(T1.x) : __float_as_uint(T1.y);
-        tp = reinterpret_cast<const float4*>(S.texs + ti);
-        T0 = tp[0];
-        T1 = tp[1];
+        load_record(L, L.texs, S.texs, ti, T0, T1);
         kind = __float_as_uint(T0.x) & 0xFFu;
     }
     if (kind == TK_NOISE) {  // texture.rs:78-82
@@ -783,9 +803,9 @@ DEV bool scatter(const Material& M, f3 color, f3 wd, const Record& rec, Rng& rng
     }
 }
 
-DEV Material load_material(const Scene& S, uint32_t mi) {
-    const float4* mp = reinterpret_cast<const float4*>(S.mats + mi);
-    float4 m0 = mp[0], m1 = mp[1];
+DEV Material load_material(const Scene& S, const LdsTables& L, uint32_t mi) {
+    float4 m0, m1;
+    load_record(L, L.mats, S.mats, mi, m0, m1);
     Material M;
     M.kind = __float_as_uint(m0.x);
     M.tex = __float_as_uint(m0.y);

@@ -121,6 +121,9 @@ struct Scene {
     uint32_t flat, world_first, world_count;
     uint32_t stack_cap;  // entries of the per-lane traversal stack the kernels are launched with (LDS, dynamic)
     uint32_t n_perlin;   // Perlin tables; the shading kernels keep table 0 in LDS when there is one
+    // lds_scene != 0: the scene is small enough that the shading kernels also keep the primitive, material and
+    // texture records in LDS (n_prims, n_mats, n_texs records of 32 bytes each)
+    uint32_t lds_scene, n_mats, n_texs;
 };
 
 }  // namespace rtd

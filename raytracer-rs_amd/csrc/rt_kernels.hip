@@ -113,13 +113,17 @@ DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderCons
     if (h.prim & HIT_MEDIUM_BIT)
         mi = S.groups[h.prim & 0x3FFFFFFFu].mat;
     else
-        mi = __float_as_uint(reinterpret_cast<const float4*>(S.prims + h.prim)[1].y) >> 8;
-    const Material M = load_material(S, mi);
+    {
+        float4 A, B;
+        load_record(tabs, tabs.prims, S.prims, h.prim, A, B);
+        mi = __float_as_uint(B.y) >> 8;
+    }
+    const Material M = load_material(S, tabs, mi);
     Record rec;
     if (material_needs_uv(M))
-        make_record<true>(S, p.o, p.d, p.time, h, rec);
+        make_record<true>(S, tabs, p.o, p.d, p.time, h, rec);
     else
-        make_record<false>(S, p.o, p.d, p.time, h, rec);
+        make_record<false>(S, tabs, p.o, p.d, p.time, h, rec);
     Rng rng{p.k0, p.k1, bounce << 24};
     f3 att{1.0f, 1.0f, 1.0f}, dir{0.0f, 0.0f, 0.0f};
     const f3 color = material_color(S, tabs, M, rec);
@@ -166,16 +170,31 @@ DEV void compact_store(CompactLds& lds, uint32_t parity, bool alive, const PathR
     }
 }
 
-// Copies Perlin table 0 into the block's dynamic LDS behind the traversal stacks (the launchers size the
-// allocation for it when the scene has a noise texture).  Must be reached by every thread of the block.
+// Fills the block's dynamic LDS behind the traversal stacks with the tables of LdsTables (the launchers size the
+// allocation: table_bytes).  Must be reached by every thread of the block.
+DEV void copy_words(uint32_t* dst, const void* src, uint32_t words) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    for (uint32_t i = threadIdx.x; i < words; i += rtk::BLOCK) dst[i] = s[i];
+}
 DEV LdsTables stage_tables(const Scene& S, uint32_t* dyn_lds) {
-    uint32_t* dst = dyn_lds + S.stack_cap * rtk::BLOCK;
-    LdsTables L{(LdsPerlinTable*)dst, S.n_perlin != 0u};
+    uint32_t* at = dyn_lds + S.stack_cap * rtk::BLOCK;
+    LdsTables L;
+    L.perlin0 = (LdsPerlinTable*)at;
+    L.has_perlin0 = S.n_perlin != 0u;
     if (S.n_perlin) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(S.perlin);
-        for (uint32_t i = threadIdx.x; i < sizeof(PerlinTable) / 4u; i += rtk::BLOCK) dst[i] = src[i];
-        __syncthreads();
+        copy_words(at, S.perlin, sizeof(PerlinTable) / 4u);
+        at += sizeof(PerlinTable) / 4u;
     }
+    L.has_scene = S.lds_scene != 0u;
+    L.prims = (LdsFloat4*)at;
+    L.mats = (LdsFloat4*)(at + 8u * S.n_prims);
+    L.texs = (LdsFloat4*)(at + 8u * (S.n_prims + S.n_mats));
+    if (S.lds_scene) {
+        copy_words(at, S.prims, 8u * S.n_prims);
+        copy_words(at + 8u * S.n_prims, S.mats, 8u * S.n_mats);
+        copy_words(at + 8u * (S.n_prims + S.n_mats), S.texs, 8u * S.n_texs);
+    }
+    if (S.n_perlin || S.lds_scene) __syncthreads();
     return L;
 }
 
@@ -469,6 +488,11 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
                                                                  float* uv, float* point, uint32_t* overflow_flag) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
     uint32_t* stk = stack + threadIdx.x;
+    LdsTables no_tables;  // this kernel stages nothing: every record comes from global memory
+    no_tables.has_perlin0 = false;
+    no_tables.has_scene = false;
+    no_tables.perlin0 = nullptr;
+    no_tables.prims = no_tables.mats = no_tables.texs = nullptr;
     for (unsigned long long i = (unsigned long long)blockIdx.x * rtk::BLOCK + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * rtk::BLOCK) {
         f3 wo{ox[i], oy[i], oz[i]}, wd{dx[i], dy[i], dz[i]};
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
         rec.normal = {0, 0, 0};
         rec.u = rec.v = 0.0f;
         rec.front = false;
-        if (hit) make_record<true>(S, wo, wd, time, h, rec);
+        if (hit) make_record<true>(S, no_tables, wo, wd, time, h, rec);
         if (prim) {
             int32_t id = -1;
             if (hit) {
@@ -583,7 +607,10 @@ namespace rtk {
 // LDS bytes of the per-lane traversal stacks of one block
 inline size_t stack_bytes(const Scene& scene) { return (size_t)std::max(1u, scene.stack_cap) * BLOCK * sizeof(uint32_t); }
 // LDS bytes of the tables a shading kernel stages (stage_tables)
-inline size_t table_bytes(const Scene& scene) { return scene.n_perlin ? sizeof(PerlinTable) : 0; }
+inline size_t table_bytes(const Scene& scene) {
+    return (scene.n_perlin ? sizeof(PerlinTable) : 0) +
+           (scene.lds_scene ? 32u * (size_t)(scene.n_prims + scene.n_mats + scene.n_texs) : 0);
+}
 
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q) {
     unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
