@@ -247,6 +247,7 @@ def main():
             trace_ms = sum(st["trace_ms"] for s in stats for st in s)
             shade_ms = sum(st["shade_ms"] for s in stats for st in s)
             bounce_ms = sum(st["bounce_ms"] for s in stats for st in s)
+            tail_ms = sum(st["tail_ms"] for s in stats for st in s)
             # per-ray node fetches / primitive tests of this workload: one instrumented pass at 1 spp (untimed)
             tr_bytes = sh_bytes = bo_bytes = 0.0
             for f, st_frame in zip(frames, zip(*stats)):
@@ -255,7 +256,8 @@ def main():
                 f.ctx.profile(events=True, count_visits=False)
                 nodes_pr = st["node_visits"] / max(st["rays"], 1)
                 prims_pr = st["prim_tests"] / max(st["rays"], 1)
-                f_rays = sum(s["rays"] for s in st_frame)
+                # rays the tail kernel finished (the last few live paths of a batch) are timed apart from the per-bounce kernels
+                f_rays = sum(s["rays"] - s["tail_rays"] for s in st_frame)
                 f_paths = sum(s["paths"] for s in st_frame)
                 alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
                 mode = st_frame[0]["pipeline"]  # 0 split, 1 fused, 2 hybrid: camera rays fused, scattered rays split
@@ -286,7 +288,7 @@ def main():
                     # path-state stream (plus one scene read per XCD and launch) is charged to HBM
                     "scene_resident_in_l2": all(f.info["device_bytes"] <= L2_PER_XCD for f in frames),
                     "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
-                    "bounce_ms_per_step": round(bounce_ms / args.steps, 3)}
+                    "bounce_ms_per_step": round(bounce_ms / args.steps, 3), "tail_ms_per_step": round(tail_ms / args.steps, 3)}
         out = {
             "metric": "Mrays/s (paths x bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -25,6 +25,20 @@ def stats(path, out, title, command):
     rows = list(csv.DictReader(open(path)))
     lines = ["# %s" % title, "", "Command (on the MI355X box): `%s`" % command, "",
              "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    # all template instances of one kernel together (bench.py times them as one kernel), without the instrumented
+    # instances (second template argument true) that bench.py only runs in its untimed counting pass
+    fams = {}
+    for r in rows:
+        name = short(r["Name"])
+        if name.startswith("k_") and "<" in name:
+            args = name[name.index("<") + 1:].rstrip(">").split(",")
+            if len(args) > 1 and args[1].strip() == "true":
+                continue
+            f = fams.setdefault(name[:name.index("<")], [0, 0.0])
+            f[0] += int(r["Calls"])
+            f[1] += float(r["TotalDurationNs"])
+    for name, (calls, ns) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
+        lines.append("| **%s, all timed instances** | %d | %.2f | %.2f | |" % (name, calls, ns / 1e6, ns / calls / 1e3))
     for r in rows:
         lines.append("| %s | %s | %.2f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                         float(r["AverageNs"]) / 1e3, r["Percentage"]))

@@ -349,6 +349,28 @@ def test_flat_and_tree_tracing_give_the_same_bits(name, monkeypatch):
         assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
 
 
+@pytest.mark.parametrize("name", ["two_perlin_spheres", "two_spheres", "cornell_smoke", "final_scene"])
+def test_lds_staged_tables_change_no_bit(name, monkeypatch):
+    """The shading kernels copy Perlin table 0 (any scene with a noise texture) and, for small scenes, the
+    primitive / material / texture records into LDS.  Where a record is read from must not change a bit."""
+    w, h, spp = 128, 96, 4
+    out = []
+    for staged in ("1", "0"):
+        monkeypatch.setenv("RTAMD_LDS_TABLES", staged)
+        ctx = rtamd.Context(0)
+        ctx.set_tail_paths(2048)
+        ctx.load_scene(name, seed=1)
+        res = []
+        for pipe in (0, 1):
+            ctx.set_pipeline(pipe)
+            img, st = ctx.render(w, h, ctx.preset_camera(w / h), spp, seed=13)
+            res += [img, np.array([st["rays"]])]
+        ctx.close()
+        out.append(res)
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
 def test_device_and_host_accumulators_agree(gpu_ctx):
     import torch
     gpu_ctx.load_scene("cornell_box", seed=1)
