@@ -26,6 +26,9 @@
 
 namespace {
 
+#ifndef BOUNCE_WAVES
+#define BOUNCE_WAVES 5
+#endif
 struct PathRegs {
     f3 o, d, T;
     float time;
@@ -215,7 +218,7 @@ DEV uint32_t primary_count(uint32_t n, uint32_t s) {
 // Held to 128 VGPRs (4 waves per SIMD): one more resident wave than the compiler's own choice hides more of
 // the queue loads and the compaction barrier than the few spilled values cost.
 template <bool GROUPS, bool COUNT, bool PRIMARY>
-__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : 5))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
+__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : BOUNCE_WAVES))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
                                                         rtk::PathState out, rtk::Queues q, uint32_t bounce,
                                                         float4* __restrict__ radiance, unsigned long long* stats,
                                                         uint32_t* overflow_flag) {
