@@ -107,3 +107,81 @@ def test_device_and_host_trees_give_the_same_bits(name, n_synth, w):
     assert (out[0][0] >= 0).mean() > 0.05  # the batch does hit things
     for a, b in zip(*out):
         assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
+
+
+# ---- degenerate inputs ------------------------------------------------------------------------------------
+def _raw_scene(ctx, builder, c0r, rects=None, moving=None):
+    import ctypes as C
+    t = rtamd.rt_texture(kind=0, color=(C.c_float * 3)(0.5, 0.5, 0.5))
+    m = rtamd.rt_material(kind=0, tex=0)
+    n = len(c0r)
+    sph = dict(c0r=c0r, mat=np.zeros(n, np.uint32), id=np.arange(n, dtype=np.uint32))
+    if moving is not None:
+        sph.update(c1=moving[0], t01=moving[1], moving=moving[2])
+    if rects is not None:
+        rects = dict(rects, mat=np.zeros(len(rects["k"]), np.uint32), id=np.arange(n, n + len(rects["k"]), dtype=np.uint32))
+    ctx.set_builder(builder)
+    ctx.set_scene(spheres=sph, rects=rects, materials=[m], textures=[t])
+    return ctx.info()
+
+
+def _ray_fan(rng, n, origin, spread):
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    o = (np.asarray(origin, np.float32)[None, :] + rng.normal(0, spread, (n, 3))).astype(np.float32)
+    return np.concatenate([o.T, d.T, rng.uniform(0, 1, (1, n)).astype(np.float32)]).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["two", "identical", "collinear", "mixed_moving_rects"])
+def test_device_builder_on_degenerate_worlds(case, monkeypatch):
+    """Worlds that stress the Morton sort: two primitives, thousands of identical ones (all keys equal, ties broken by
+    index), centres on one line (two axes without extent), and a mix of rects and moving spheres.  The device tree
+    must give the hits of the host tree (flat tracing is off, so both really walk a tree)."""
+    monkeypatch.setenv("RTAMD_FLAT_MAX", "0")
+    rng = np.random.default_rng(7)
+    rects = moving = None
+    if case == "two":
+        c0r = np.float32([[0, 0, 0, 1], [3, 0, 0, 1]])
+    elif case == "identical":
+        c0r = np.tile(np.float32([[1, 2, 3, 0.5]]), (3000, 1))
+    elif case == "collinear":
+        c0r = np.stack([np.linspace(-50, 50, 4000), np.zeros(4000), np.zeros(4000), np.full(4000, 0.01)], 1).astype(np.float32)
+    else:
+        n = 3000
+        c0r = np.concatenate([rng.uniform(-20, 20, (n, 3)), rng.uniform(0.05, 0.6, (n, 1))], 1).astype(np.float32)
+        c1 = (c0r[:, :3] + rng.uniform(-1, 1, (n, 3))).astype(np.float32)
+        moving = (c1, np.tile(np.float32([[0.0, 1.0]]), (n, 1)), (rng.uniform(0, 1, n) < 0.5).astype(np.uint8))
+        m = 2000
+        lo = rng.uniform(-20, 19, (m, 2))
+        rects = dict(axis=rng.integers(0, 3, m).astype(np.uint8), k=rng.uniform(-20, 20, m).astype(np.float32),
+                     bounds=np.concatenate([lo, lo + rng.uniform(0.1, 1.0, (m, 2))], 1).astype(np.float32))
+    rays = _ray_fan(rng, 30000, c0r[:, :3].mean(0), 2.0 * c0r[:, :3].std(0).max() + 1.0)
+    out = []
+    for builder in (0, 1):
+        ctx = rtamd.Context(0)
+        info = _raw_scene(ctx, builder, c0r, rects, moving)
+        assert info["builder"] == builder and info["stack_entries"] <= 64
+        hit = ctx.intersect(rays, seed=1)
+        out.append([hit["prim"], hit["t"], hit["normal"], hit["front"]])
+        ctx.close()
+    assert (out[0][0] >= 0).any()
+    if case == "identical":  # exact ties everywhere: the highest id wins (scene.rs:32-38, "later shape wins")
+        assert set(np.unique(out[1][0]).tolist()) <= {-1, 2999}
+    for a, b in zip(*out):
+        assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
+
+
+def test_empty_world_renders_the_background():
+    """A Scene with no shapes: every ray misses (main.rs:60-62), every pixel holds spp sequential adds of the background."""
+    ctx = rtamd.Context(0)
+    ctx.set_scene()
+    assert ctx.info()["n_prims"] == 0
+    hit = ctx.intersect(_ray_fan(np.random.default_rng(1), 100, (0, 0, 0), 1.0))
+    assert np.all(hit["prim"] == -1) and np.all(np.isinf(hit["t"]))
+    cam = rtamd.camera_new((0, 0, -5), (0, 0, 0), (0, 1, 0), 0.5, 1.5, 0.0, 10.0, 0.0, 1.0)
+    bg = np.float32([0.25, 0.5, 0.75])
+    img, st = ctx.render(33, 22, cam, 5, background=bg)
+    acc = np.zeros(3, np.float32)
+    for _ in range(5):
+        acc = acc + bg
+    assert st["rays"] == st["paths"] == 33 * 22 * 5 and np.all(img == acc)
+    ctx.close()
