@@ -86,6 +86,7 @@ struct rt_ctx {
     int builder = -1;  // world-level BVH: -1 by size, 0 host (binned SAH), 1 device (linear BVH)
     uint64_t gpu_build_min = 1u << 18;  // builder -1: worlds with at least this many primitives are built on the device
     uint64_t tail_paths = 256u << 10;  // a batch with at most this many live paths is finished by one k_finish launch
+    rtk::SpillArea trace_spill;  // deep traversal-stack entries of k_trace (launch_trace grows it)
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
     uint64_t n_owned = 0;
@@ -352,6 +353,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_rays) (void)hipHostFree(c->h_rays);
+    if (c->trace_spill.p) (void)hipFree(c->trace_spill.p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1086,7 +1088,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                     } else {
                         {
                             ScopedTimer tm(c, KS_TRACE);
-                            HIP_TRY(c, rtk::launch_trace(c->stream, tcfg, c->scene, in, q, b, bps, (float4*)c->d_hits.p, d_stats, d_ovf));
+                            HIP_TRY(c, rtk::launch_trace(c->stream, tcfg, c->scene, in, q, b, bps, (float4*)c->d_hits.p, d_stats, d_ovf, c->trace_spill));
                         }
                         {
                             ScopedTimer tm(c, KS_SHADE);

@@ -375,6 +375,28 @@ DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tmin, float tbest, float& tn) {
     return (pad_down(n) <= fp) && (fp >= tmin) && (pad_down(n) <= tbest);
 }
 
+// Per-lane traversal stack.  The first lds_cap entries live in LDS, laid out [entry][lane] (conflict free).
+// Walking the near child first keeps the stack shallow, so a kernel may give LDS to the first few entries
+// only (more resident blocks per CU) and send the rare deeper ones to a global spill area laid out
+// [entry][thread]; spill == nullptr means that all S.stack_cap entries are in LDS.
+struct Stack {
+    uint32_t* lds;    // this lane's column
+    uint32_t lds_cap;
+    uint32_t* spill;  // this thread's column
+    uint32_t spill_stride;
+};
+template <int STRIDE>
+DEV void stack_put(const Stack& st, int sp, uint32_t v) {
+    if ((uint32_t)sp < st.lds_cap)
+        st.lds[sp * STRIDE] = v;
+    else
+        st.spill[(size_t)((uint32_t)sp - st.lds_cap) * st.spill_stride] = v;
+}
+template <int STRIDE>
+DEV uint32_t stack_get(const Stack& st, int sp) {
+    if ((uint32_t)sp < st.lds_cap) return st.lds[sp * STRIDE];
+    return st.spill[(size_t)((uint32_t)sp - st.lds_cap) * st.spill_stride];
+}
 // Short-stack traversal of the two-level BVH.  stk points at this lane's column of the LDS stack;
 // consecutive entries are STRIDE words apart so that the 64 lanes of a wave hit 64 different banks.
 struct TraceCount {
@@ -406,7 +428,7 @@ DEV bool walk_done(const Walk& w) { return w.cur == REF_EMPTY; }
 // Walks inner nodes only (at most max_steps of them), until cur is a leaf, an instance, a sentinel or empty.
 // Near child first; a box is entered only if it can still hold a hit at or before the closest one.
 template <int STRIDE, bool COUNT>
-DEV void walk_inner(const Scene& S, Walk& w, float tmin, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
+DEV void walk_inner(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
     for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) {
         const float4* np = reinterpret_cast<const float4*>(S.nodes + w.cur);
         float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
@@ -422,7 +444,7 @@ DEV void walk_inner(const Scene& S, Walk& w, float tmin, uint32_t* stk, uint32_t
             w.cur = first1 ? c1 : c0;
             if (h0 && h1) {
                 if (w.sp < (int)S.stack_cap) {
-                    stk[w.sp * STRIDE] = first1 ? c0 : c1;
+                    stack_put<STRIDE>(stk, w.sp, first1 ? c0 : c1);
                     w.sp++;
                 } else {
                     *overflow_flag = 1u;
@@ -430,7 +452,7 @@ DEV void walk_inner(const Scene& S, Walk& w, float tmin, uint32_t* stk, uint32_t
             }
         } else if (w.sp > 0) {
             w.sp--;
-            w.cur = stk[w.sp * STRIDE];
+            w.cur = stack_get<STRIDE>(stk, w.sp);
         } else {
             w.cur = REF_EMPTY;
         }
@@ -439,7 +461,7 @@ DEV void walk_inner(const Scene& S, Walk& w, float tmin, uint32_t* stk, uint32_t
 // One non-inner step: tests a leaf's primitives, enters an instance or leaves it, then takes the next entry
 // from the stack.  No-op when cur is an inner node or empty.
 template <int STRIDE, bool GROUPS, bool COUNT>
-DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin, uint32_t* stk, uint32_t* overflow_flag,
+DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin, const Stack& stk, uint32_t* overflow_flag,
                    TraceCount* cnt) {
     const uint32_t type = w.cur >> 30;
     if (w.cur == REF_EMPTY || type == REF_INNER) return;
@@ -461,7 +483,7 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
                     w.a = dot3(w.d, w.d);
                     w.inv = fast_rcp3(w.d);
                 }
-                stk[w.sp * STRIDE] = REF_SENTINEL;
+                stack_put<STRIDE>(stk, w.sp, REF_SENTINEL);
                 w.sp++;
                 w.grp = (int)g;
                 w.cur = root;
@@ -479,7 +501,7 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
     }
     if (w.cur == REF_EMPTY && w.sp > 0) {  // next entry from the stack
         w.sp--;
-        w.cur = stk[w.sp * STRIDE];
+        w.cur = stack_get<STRIDE>(stk, w.sp);
     }
 }
 // ConstantMedium objects come after all surfaces, in creation order (the order of a Scene whose media were
@@ -526,7 +548,7 @@ DEV void trace_flat(const Scene& S, f3 wo, f3 wd, float time, float tmin, float 
 // are still descending do not drag the (long) primitive tests of the others along on every iteration.
 template <int STRIDE, bool GROUPS, bool COUNT = false>
 DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
-                   uint32_t bounce, Hit& best, uint32_t* stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
+                   uint32_t bounce, Hit& best, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
     if (S.flat) {
         trace_flat<GROUPS, COUNT>(S, wo, wd, time, tmin, tmax, best, cnt);
         if (GROUPS) apply_media<COUNT>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);

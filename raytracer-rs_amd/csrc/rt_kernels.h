@@ -56,9 +56,14 @@ struct TraceCfg {
 
 // ---- split pipeline: raygen, then per bounce trace + shade --------------------------------------------
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q);
+// Global memory behind the LDS part of k_trace's traversal stacks; grown by launch_trace as needed, owned by the caller.
+struct SpillArea {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
 hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, PathState in, Queues q,
                         uint32_t bounce, uint32_t blocks_per_shard, float4* hits, unsigned long long* stats,
-                        uint32_t* overflow_flag);
+                        uint32_t* overflow_flag, SpillArea& spill);
 hipError_t launch_shade(hipStream_t s, const rtd::Scene& scene, const RenderConst& rc, PathState in, PathState out,
                         const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance);
 // ---- fused pipeline: one kernel per bounce (bounce 0 generates its camera rays itself) ---------------------

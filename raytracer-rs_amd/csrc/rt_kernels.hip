@@ -233,7 +233,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
         q.counts[((bounce + 2u) % 3u) * rtk::NSHARD + shard] = 0;  // the next bounce appends there
         if (n) atomicAdd(stats, (unsigned long long)n);
     }
-    uint32_t* stk = stack + threadIdx.x;
+    const Stack stk{stack + threadIdx.x, S.stack_cap, nullptr, 0u};
     const LdsTables L = stage_tables(S, stack);
     TraceCount tc{0u, 0u};
     uint32_t parity = 0;
@@ -311,8 +311,9 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
 template <bool GROUPS, bool COUNT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
-                                                       uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
+                                                       uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS, uint32_t lds_entries,
+                                                       uint32_t* spill) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // lds_entries entries per lane, [entry][lane]; deeper ones spill
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     const uint32_t shard_base = shard * q.cap_shard;
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
         q.counts[((bounce + 2u) % 3u) * rtk::NSHARD + shard] = 0;
         if (n) atomicAdd(stats, (unsigned long long)n);
     }
-    uint32_t* stk = stack + threadIdx.x;
+    // blockIdx.x * BLOCK + threadIdx.x is this thread's column of the spill area (gridDim.x * BLOCK columns)
+    const Stack stk{stack + threadIdx.x, lds_entries, spill + (size_t)blockIdx.x * rtk::BLOCK + threadIdx.x, gridDim.x * (uint32_t)rtk::BLOCK};
     TraceCount tc{0u, 0u};
     if (S.flat) {  // no tree, no divergence between rays: plain strided loop
         for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     const uint32_t shard_base = shard * q.cap_shard;
-    uint32_t* stk = stack + threadIdx.x;
+    const Stack stk{stack + threadIdx.x, S.stack_cap, nullptr, 0u};
     const LdsTables L = stage_tables(S, stack);
     uint32_t rays = 0;
     for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
                                                                  int32_t* inst, float* t, float* normal, uint8_t* front,
                                                                  float* uv, float* point, uint32_t* overflow_flag) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
-    uint32_t* stk = stack + threadIdx.x;
+    const Stack stk{stack + threadIdx.x, S.stack_cap, nullptr, 0u};
     LdsTables no_tables;  // this kernel stages nothing: every record comes from global memory
     no_tables.has_perlin0 = false;
     no_tables.has_scene = false;
@@ -622,15 +624,36 @@ hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batc
     return hipGetLastError();
 }
 
+// Entries of the traversal stack k_trace keeps in LDS; deeper entries spill to global memory.  The walk takes
+// the near child first, so a ray rarely holds more than a few entries, while LDS sized for the worst case
+// (tree depth) is what limits the resident waves of this latency-bound kernel.
+uint32_t trace_lds_entries(const Scene& scene) {
+    static const int v = env_factor("RTAMD_STACK_LDS", 8);
+    return std::min<uint32_t>(std::max(1u, scene.stack_cap), (uint32_t)v);
+}
 hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, PathState in, Queues q, uint32_t bounce,
-                        uint32_t blocks_per_shard, float4* hits, unsigned long long* stats, uint32_t* overflow_flag) {
+                        uint32_t blocks_per_shard, float4* hits, unsigned long long* stats, uint32_t* overflow_flag,
+                        SpillArea& spill) {
     const dim3 block(BLOCK);
-    const size_t smem = stack_bytes(scene);
-#define RT_CALL(G, C)                                                                                                       \
-    hipLaunchKernelGGL((k_trace<G, C>),                                                                                     \
-                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C>, trace_oversubscription(), smem)), block, \
-                       smem, s, scene, in, q, bounce, hits, stats, overflow_flag, (uint32_t)env_factor("RTAMD_REFILL", 24), \
-                       env_factor("RTAMD_INNER_STEPS", 4))
+    const uint32_t lds_entries = trace_lds_entries(scene);
+    const size_t smem = (size_t)lds_entries * BLOCK * sizeof(uint32_t);
+    const uint32_t deep = std::max(1u, scene.stack_cap) - lds_entries;
+#define RT_CALL(G, C)                                                                                                            \
+    do {                                                                                                                         \
+        const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C>, trace_oversubscription(), smem);            \
+        const size_t need = (size_t)deep * grid * BLOCK * sizeof(uint32_t);                                                      \
+        if (need > spill.bytes) {                                                                                                \
+            if (spill.p) (void)hipFree(spill.p);                                                                                 \
+            spill.p = nullptr;                                                                                                   \
+            spill.bytes = 0;                                                                                                     \
+            hipError_t e = hipMalloc(&spill.p, need);                                                                            \
+            if (e != hipSuccess) return e;                                                                                       \
+            spill.bytes = need;                                                                                                  \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((k_trace<G, C>), dim3(grid), block, smem, s, scene, in, q, bounce, hits, stats, overflow_flag,        \
+                           (uint32_t)env_factor("RTAMD_REFILL", 24), env_factor("RTAMD_INNER_STEPS", 4), lds_entries,            \
+                           (uint32_t*)spill.p);                                                                                  \
+    } while (0)
     RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
 #undef RT_CALL
     return hipGetLastError();
