@@ -289,6 +289,12 @@ def main():
                     "scene_resident_in_l2": all(f.info["device_bytes"] <= L2_PER_XCD for f in frames),
                     "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
                     "bounce_ms_per_step": round(bounce_ms / args.steps, 3), "tail_ms_per_step": round(tail_ms / args.steps, 3)}
+            if achieved > PEAK_HBM_GBPS:
+                # only for scenes beyond L2 (64 B per node fetch charged to HBM): every ray walks the same upper
+                # levels of the tree, which L2 and the 256 MB MALL serve, so the algorithmic figure can exceed what HBM
+                # delivers; the measured traffic (profiles/) is the number to read there
+                roof["note"] = "algorithmic node bytes exceed the HBM peak: upper tree levels are served by L2/MALL"
+
         out = {
             "metric": "Mrays/s (paths x bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

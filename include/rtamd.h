@@ -47,8 +47,8 @@ int rt_ctx_synchronize(rt_ctx* ctx);
  * a shade kernel per bounce), 1 = fused (one kernel per bounce), 2 = hybrid (bounce 0 fused, later bounces
  * split).  All produce the same bits. */
 int rt_ctx_set_pipeline(rt_ctx* ctx, int pipeline);
-/* Once a batch has at most tail_paths live paths, one kernel launch walks each of them to its end instead of
- * one launch per bounce (default 262144, env RTAMD_TAIL_PATHS; 0 = never).  The image does not depend on it. */
+/* Once a batch has at most tail_paths live paths, one kernel launch walks each of them to its end
+ * instead of one launch per bounce (default 262144, env RTAMD_TAIL_PATHS; 0 = never).  The image does not depend on it. */
 int rt_ctx_set_tail_paths(rt_ctx* ctx, uint64_t tail_paths);
 
 /* ---- scene description --------------------------------------------------

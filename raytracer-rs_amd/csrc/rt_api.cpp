@@ -536,7 +536,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     auto id_of = [&](const PrimSrc& s) { return s.sphere ? c->sph.id[s.idx] : c->rect.id[s.idx]; };
     for (auto& v : members) std::sort(v.begin(), v.end(), [&](const PrimSrc& a, const PrimSrc& b) { return id_of(a) < id_of(b); });
 
-    const uint32_t leaf_max = std::max(1u, std::min(env_u32("RTAMD_LEAF_MAX", 4), rtd::MAX_LEAF_PRIMS));
+    const uint32_t leaf_max = std::max(1u, std::min(env_u32("RTAMD_LEAF_MAX", 1), rtd::MAX_LEAF_PRIMS));
     std::vector<rtd::Node> nodes;
     std::vector<rtd::Prim> prims;
     std::vector<rtd::Moving> moving;
@@ -1111,7 +1111,10 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                         if (longest == 0) break;
                         bps = (longest + rtk::BLOCK - 1) / rtk::BLOCK;
                         if (live <= c->tail_paths && !c->count_visits) {
-                            // few paths left: one launch walks each of them to its end (same draws, same bits)
+                            // few paths left: one launch walks each of them to its end (same draws, same bits).  The
+                            // tail takes about as long as its longest path run serially (0.1 ms on a flat scene, ~0.9 ms
+                            // through a tree), which is still well below the ~45 launches + read-backs it replaces
+                            // (C1, 400x225x10: 3.1 -> 1.4 ms per frame).
                             ScopedTimer tm(c, KS_TAIL);
                             HIP_TRY(c, rtk::launch_finish(c->stream, tcfg, c->scene, rcst, out, q, b + 1, bps, d_rad, d_stats, d_ovf));
                             st.tail_launches++;
