@@ -207,6 +207,13 @@ def main():
               for n in frames_cfg]
     for f in frames:
         f.ctx.profile(events=not args.no_profile)
+        # set-up, not work: path queues allocated, pixel list uploaded and kernels loaded before the timed region,
+        # whatever --warmup says (one 1-spp pass of this rank's tiles; the frame is rendered again from zero)
+        f.ctx.reserve(len(rtamd.owned_pixels(f.w, f.h, f.tile, rank, world)) * spp)
+        f.render(spp=1, exchange=False)
+    if world > 1 and args.backend == "nccl":
+        # first collective builds the RCCL communicator: keep that out of the timed steps as well
+        torch.distributed.all_reduce(torch.zeros(1, device=f"cuda:{local_rank}"))
 
     def barrier():
         if world > 1:

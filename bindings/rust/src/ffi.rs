@@ -136,6 +136,7 @@ extern "C" {
     pub fn rt_last_error(ctx: *const rt_ctx) -> *const c_char;
     pub fn rt_ctx_set_stream(ctx: *mut rt_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn rt_ctx_set_max_paths(ctx: *mut rt_ctx, max_paths: u64) -> c_int;
+    pub fn rt_ctx_reserve(ctx: *mut rt_ctx, n_paths: u64) -> c_int;
     pub fn rt_ctx_synchronize(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_ctx_set_pipeline(ctx: *mut rt_ctx, pipeline: c_int) -> c_int;
     pub fn rt_ctx_set_tail_paths(ctx: *mut rt_ctx, tail_paths: u64) -> c_int;

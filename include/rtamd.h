@@ -42,6 +42,9 @@ int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
 /* Upper bound on paths in flight per wavefront batch (default 512Mi paths = up to 72 GB of wavefront buffers,
  * never more than 60% of the free device memory; env RTAMD_MAX_PATHS_MI).  A render allocates only what it needs. */
 int rt_ctx_set_max_paths(rt_ctx* ctx, uint64_t max_paths);
+/* Allocates the path queues for renders of up to n_paths camera samples (pixels x samples of one call) now, so
+ * that the first rt_render does not pay for it.  Optional: rt_render grows the buffers itself when it has to. */
+int rt_ctx_reserve(rt_ctx* ctx, uint64_t n_paths);
 int rt_ctx_synchronize(rt_ctx* ctx);
 /* Kernel pipeline of rt_render: -1 = pick per scene (default), 0 = split (ray generation, then a trace and
  * a shade kernel per bounce), 1 = fused (one kernel per bounce), 2 = hybrid (bounce 0 fused, later bounces

@@ -276,6 +276,25 @@ rtk::PathState path_state(rt_ctx* c, int s) {
     return p;
 }
 
+// Wavefront buffers for a render of n_paths camera samples: one batch if it fits, else the largest that does.
+// Large batches amortise the per-bounce launches and tails (one batch of 512 Mi paths renders a 1080p frame at
+// 256 spp ~20% faster than eight of 64 Mi), but they must fit: at most 60% of what the device has free now plus
+// what the wavefront buffers already hold (144 bytes per path).
+int reserve_paths(rt_ctx* c, uint64_t n_paths, bool need_hits) {
+    uint64_t cap = std::min<uint64_t>(c->max_paths, n_paths);
+    if (cap > c->capacity) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t held = c->capacity * 144ull;
+            const uint64_t fit = (uint64_t)(0.6 * (double)(free_b + held)) / 144ull;
+            cap = std::min<uint64_t>(cap, std::max<uint64_t>(fit, 1ull << 20));
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return alloc_wavefront(c, std::max<uint64_t>(cap, 1024), need_hits);
+}
+
 // ---- event profiling -------------------------------------------------------------
 int ev_get(rt_ctx* c, int& idx) {
     if (c->ev_next == c->ev_pool.size()) {
@@ -379,6 +398,11 @@ int rt_ctx_set_builder(rt_ctx* c, int builder) {
     if (!c || builder < -1 || builder > 1) return fail(c, RT_ERR_INVALID, "builder must be -1, 0 or 1");
     c->builder = builder;
     return RT_OK;
+}
+int rt_ctx_reserve(rt_ctx* c, uint64_t n_paths) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return reserve_paths(c, n_paths, true);
 }
 int rt_ctx_set_tail_paths(rt_ctx* c, uint64_t tail_paths) {
     if (!c) return RT_ERR_INVALID;
@@ -1040,21 +1064,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     const bool fused = mode == 1;
     st.pipeline = (uint32_t)mode;
     if (n_owned && n_samples_total) {
-        uint64_t cap = std::min<uint64_t>(c->max_paths, n_owned * (uint64_t)n_samples_total);
-        if (cap > c->capacity) {
-            // Large batches amortise the per-bounce launches and tails (one batch of 512 Mi paths renders a
-            // 1080p frame at 256 spp ~20% faster than eight of 64 Mi), but they must fit: at most 60% of what
-            // the device has free now plus what the wavefront buffers already hold (144 bytes per path).
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const uint64_t held = c->capacity * 144ull;
-                const uint64_t fit = (uint64_t)(0.6 * (double)(free_b + held)) / 144ull;
-                cap = std::min<uint64_t>(cap, std::max<uint64_t>(fit, 1ull << 20));
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-        if ((rc = alloc_wavefront(c, std::max<uint64_t>(cap, 1024), !fused))) return rc;
+        if ((rc = reserve_paths(c, n_owned * (uint64_t)n_samples_total, !fused))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 128, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
         const rtk::Queues q{(uint32_t*)c->d_counts.p, c->cap_shard};

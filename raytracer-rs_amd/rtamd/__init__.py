@@ -29,7 +29,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPP
 # every symbol include/rtamd.h declares
 ABI_SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_ctx_set_stream", "rt_ctx_set_max_paths",
-    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_set_builder", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
+    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_reserve", "rt_ctx_set_builder", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
     "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_accum_write", "rt_accum_read", "rt_owned_pixels")
@@ -121,6 +121,7 @@ def core():
     L.rt_ctx_synchronize.argtypes = [vp]
     L.rt_ctx_set_pipeline.argtypes = [vp, C.c_int]
     L.rt_ctx_set_tail_paths.argtypes = [vp, u64]
+    L.rt_ctx_reserve.argtypes = [vp, u64]
     L.rt_ctx_set_builder.argtypes = [vp, C.c_int]
     L.rt_scene_read_bvh.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u32)]
     L.rt_scene_clear.argtypes = [vp]
@@ -330,6 +331,10 @@ class Context:
         root = C.c_uint32(0)
         self._check(self.L.rt_scene_read_bvh(self.h, nodes.ctypes.data, nodes.nbytes, prims.ctypes.data, prims.nbytes, C.byref(root)))
         return nodes, prims, root.value
+
+    def reserve(self, n_paths):
+        """Allocate the path queues for renders of up to n_paths camera samples ahead of the first render."""
+        self._check(self.L.rt_ctx_reserve(self.h, int(n_paths)))
 
     def set_tail_paths(self, n):
         """Live-path count at or below which one launch finishes a batch (0 = one launch per bounce to the end)."""

@@ -153,6 +153,9 @@ def test_error_paths(gpu_ctx):
     assert "time" in str(e.value)
     img, st = ctx.render(8, 8, cam, 2, depth=253)
     assert st["rays"] >= 128 and np.isfinite(img).all()
+    ctx.reserve(1 << 20)  # queues allocated ahead of time: same image
+    img2, st2 = ctx.render(8, 8, cam, 2, depth=253)
+    assert st2["rays"] == st["rays"] and np.array_equal(img2, img)
     ctx.close()
 
 
