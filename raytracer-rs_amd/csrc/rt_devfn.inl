@@ -785,11 +785,21 @@ DEV f3 material_color(const Scene& S, const LdsTables& L, const Material& M, con
     if ((M.pad & MF_SOLID) || M.kind == MK_METAL || M.kind == MK_DIELECTRIC) return ld3(M.albedo);
     return tex_value(S, L, M.tex, rec.u, rec.v, rec.point);
 }
-// returns true when the path continues; att and the scattered direction are set then
+// returns true when the path continues; att and the scattered direction are set then.
+// Lambertian, Metal and Isotropic all start by drawing random_in_unit_sphere() from the bounce's stream
+// (vec3_helpers.rs:25-31 through materials.rs:47, 89, 206), and two of them normalise it.  A wave of scattered
+// rays holds all three kinds at once, so the rejection loop (by far the longest part of a scatter) and the
+// normalisation are done once for all of them ahead of the per-material code, not once per material.
 DEV bool scatter(const Material& M, f3 color, f3 wd, const Record& rec, Rng& rng, f3& att, f3& dir) {
+    const bool draws = M.kind == MK_LAMBERTIAN || M.kind == MK_METAL || M.kind == MK_ISOTROPIC;
+    f3 ball{0.0f, 0.0f, 1.0f}, unit_ball{0.0f, 0.0f, 1.0f};
+    if (draws) {
+        ball = rand_in_unit_sphere(rng);
+        if (M.kind != MK_METAL) unit_ball = normalize3(ball);
+    }
     switch (M.kind) {
         case MK_LAMBERTIAN: {  // materials.rs:45-61
-            f3 sc = rec.normal + normalize3(rand_in_unit_sphere(rng));
+            f3 sc = rec.normal + unit_ball;
             if (__builtin_fabsf(sc.x) < F32_EPSILON && __builtin_fabsf(sc.y) < F32_EPSILON && __builtin_fabsf(sc.z) < F32_EPSILON)
                 sc = rec.normal;
             dir = sc;
@@ -798,7 +808,7 @@ DEV bool scatter(const Material& M, f3 color, f3 wd, const Record& rec, Rng& rng
         }
         case MK_METAL: {  // materials.rs:84-95 (draws even when fuzz == 0)
             f3 reflected = reflect3(normalize3(wd), rec.normal);
-            dir = reflected + M.fuzz * rand_in_unit_sphere(rng);
+            dir = reflected + M.fuzz * ball;
             att = color;
             return dot3(dir, rec.normal) > 0.0f;
         }
@@ -816,7 +826,7 @@ DEV bool scatter(const Material& M, f3 color, f3 wd, const Record& rec, Rng& rng
             return true;
         }
         case MK_ISOTROPIC: {  // materials.rs:204-215
-            dir = normalize3(rand_in_unit_sphere(rng));
+            dir = unit_ball;
             att = color;
             return true;
         }
