@@ -427,3 +427,22 @@ def test_c5_like_deep_bvh_properties(gpu_ctx):
     for r in range(4):
         gpu_ctx.render(w, h, cam, 1, seed=1, accum=four, rank=r, nranks=4)
     assert torch.equal(one, four)
+
+
+def test_cpp_example_renders_the_same_image_as_the_python_binding(tmp_path):
+    """examples/render_main.cpp builds simple_light with the C++ mirror of the reference's constructors (as
+    main.rs:163-175 does), renders through the C ABI and writes a PNG; the named scene of the host library rendered
+    through the Python binding must give the same bytes."""
+    import subprocess
+    from PIL import Image
+    exe = orc.ROOT / "raytracer-rs_amd" / "lib" / "render_main"  # built by the Makefile next to the libraries
+    assert exe.exists(), "run make -C raytracer-rs_amd (or __graft_entry__.build()) first"
+    out = tmp_path / "test.png"
+    r = subprocess.run([str(exe), "160", "6", str(out)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0 and "Time elapsed" in r.stdout, r.stderr
+    ctx = rtamd.Context(0)
+    ctx.load_scene("simple_light", seed=1)
+    img, _ = ctx.render(160, 90, ctx.preset_camera(16 / 9), 6, seed=1)
+    ref = ctx.resolve_u8(img, 6)
+    ctx.close()
+    assert np.array_equal(np.asarray(Image.open(out)), ref)
