@@ -638,6 +638,10 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
     const uint32_t lds_entries = trace_lds_entries(scene);
     const size_t smem = (size_t)lds_entries * BLOCK * sizeof(uint32_t);
     const uint32_t deep = std::max(1u, scene.stack_cap) - lds_entries;
+    // A wave refills its free lanes from its own run of the queue, so a run of one tile gives it nothing to refill
+    // from.  When few rays are queued, launch fewer blocks rather than shorter runs: at least min_run rays per wave.
+    static const int min_run = env_factor("RTAMD_TRACE_MIN_RUN", 16) * 8;  // in units of 8 rays (env_factor caps at 64)
+    blocks_per_shard = std::max(1u, (blocks_per_shard * BLOCK + (BLOCK / 64) * min_run - 1) / ((BLOCK / 64) * min_run));
 #define RT_CALL(G, C)                                                                                                            \
     do {                                                                                                                         \
         const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C>, trace_oversubscription(), smem);            \
