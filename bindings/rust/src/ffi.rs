@@ -128,6 +128,8 @@ pub struct rt_render_stats {
     pub tail_launches: u32,
     pub tail_rays: u64,
     pub tail_ms: f64,
+    pub paths_ms: f64,
+    pub paths_launches: u64,
 }
 
 extern "C" {

@@ -48,7 +48,8 @@ int rt_ctx_reserve(rt_ctx* ctx, uint64_t n_paths);
 int rt_ctx_synchronize(rt_ctx* ctx);
 /* Kernel pipeline of rt_render: -1 = pick per scene (default), 0 = split (ray generation, then a trace and
  * a shade kernel per bounce), 1 = fused (one kernel per bounce), 2 = hybrid (bounce 0 fused, later bounces
- * split).  All produce the same bits. */
+ * split), 3 = whole paths (one launch per batch: every lane follows a path to its end and then starts the next
+ * one; no path queues).  All produce the same bits. */
 int rt_ctx_set_pipeline(rt_ctx* ctx, int pipeline);
 /* Once a batch has at most tail_paths live paths, one kernel launch walks each of them to its end
  * instead of one launch per bounce (default 262144, env RTAMD_TAIL_PATHS; 0 = never).  The image does not depend on it. */
@@ -209,6 +210,8 @@ typedef struct rt_render_stats {
     uint32_t tail_launches; /* batches whose last live paths were finished by the single-launch tail kernel */
     uint64_t tail_rays;   /* rays traced by the tail kernel (included in rays) */
     double tail_ms;       /* HIP-event time of the tail kernel (profile flag 1) */
+    double paths_ms;      /* pipeline 3: HIP-event time of the whole-path kernel (profile flag 1) */
+    uint64_t paths_launches;
 } rt_render_stats;
 
 int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* accum_rgb,

@@ -47,7 +47,7 @@ struct HostImage {
     std::vector<uint8_t> rgb;
 };
 
-enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_BOUNCE = 4, KS_TAIL = 5, KS_COUNT = 6 };
+enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_BOUNCE = 4, KS_TAIL = 5, KS_PATHS = 6, KS_COUNT = 7 };
 
 }  // namespace
 
@@ -82,6 +82,8 @@ struct rt_ctx {
     uint32_t cap_shard = 0;
     int pipeline = -1;  // -1 choose per scene, 0 split (raygen + trace + shade), 1 fused (one kernel per bounce), 2 hybrid
     int deep_pipeline = 2;  // what trees above fused_node_limit take
+    uint32_t n_perlin_tables = 0;  // of the committed scene
+    bool whole_paths_auto = true;  // pipeline -1 may pick 3 (whole paths) for flat scenes; env RTAMD_WHOLE_PATHS=0 turns that off
     uint64_t fused_node_limit = 64;  // scenes with more BVH nodes than this take deep_pipeline
     int builder = -1;  // world-level BVH: -1 by size, 0 host (binned SAH), 1 device (linear BVH)
     uint64_t gpu_build_min = 1u << 18;  // builder -1: worlds with at least this many primitives are built on the device
@@ -348,9 +350,10 @@ int rt_ctx_create(int device, rt_ctx** out) {
         return RT_ERR_HIP;
     }
     c->max_paths = (uint64_t)env_u32("RTAMD_MAX_PATHS_MI", 512) << 20;
-    if (getenv("RTAMD_PIPELINE")) c->pipeline = (int)std::min(env_u32("RTAMD_PIPELINE", 1), 2u);  // 0 split, 1 fused, 2 hybrid
+    if (getenv("RTAMD_PIPELINE")) c->pipeline = (int)std::min(env_u32("RTAMD_PIPELINE", 1), 3u);  // 0 split, 1 fused, 2 hybrid, 3 whole paths
     if (getenv("RTAMD_DEEP_PIPELINE")) c->deep_pipeline = (int)std::min(env_u32("RTAMD_DEEP_PIPELINE", 2), 2u);
     if (getenv("RTAMD_FUSED_NODE_LIMIT")) c->fused_node_limit = env_u32("RTAMD_FUSED_NODE_LIMIT", 0);
+    if (getenv("RTAMD_WHOLE_PATHS")) c->whole_paths_auto = env_u32("RTAMD_WHOLE_PATHS", 1) != 0;
     if (getenv("RTAMD_TAIL_PATHS")) c->tail_paths = env_u32("RTAMD_TAIL_PATHS", 0);
     if (getenv("RTAMD_BUILDER")) c->builder = (int)std::min(env_u32("RTAMD_BUILDER", 0), 1u);
     if (getenv("RTAMD_GPU_BUILD_MIN")) c->gpu_build_min = env_u32("RTAMD_GPU_BUILD_MIN", 0);
@@ -390,7 +393,7 @@ int rt_ctx_set_max_paths(rt_ctx* c, uint64_t max_paths) {
     return RT_OK;
 }
 int rt_ctx_set_pipeline(rt_ctx* c, int pipeline) {
-    if (!c || pipeline < -1 || pipeline > 2) return fail(c, RT_ERR_INVALID, "pipeline must be -1, 0, 1 or 2");
+    if (!c || pipeline < -1 || pipeline > 3) return fail(c, RT_ERR_INVALID, "pipeline must be -1, 0, 1, 2 or 3");
     c->pipeline = pipeline;
     return RT_OK;
 }
@@ -860,6 +863,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.n_media = n_media;
     S.flat = flat_ok ? 1u : 0u;
     S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
+    c->n_perlin_tables = n_perlin;
     S.n_perlin = env_u32("RTAMD_LDS_TABLES", 1) ? n_perlin : 0u;  // 0: noise lookups read the table from global memory
     S.n_mats = (uint32_t)c->mats.size();
     S.n_texs = (uint32_t)c->texs.size();
@@ -1059,9 +1063,16 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     // its lanes busy across rays at half the registers: final_scene (1.9k nodes) +9%, 10M spheres +55%.
     // mode 2 (hybrid): camera rays are coherent and cost no queue read, so bounce 0 runs fused; the scattered
     // rays of the later bounces go through the split kernels
-    const int mode = c->pipeline >= 0 ? c->pipeline : (c->info.n_nodes <= c->fused_node_limit ? 1 : c->deep_pipeline);
+    // flat scenes whose shading is cheap and whose paths are not held long by media go whole-path (mode 3): the path
+    // state never leaves the registers (two_spheres 50.5 -> 33.5 ms per frame).  With a noise texture or media the
+    // per-bounce kernels stay ahead: every regeneration round runs the camera code next to a shading step that is
+    // already VALU-bound (two_perlin_spheres 39 vs 43 ms), and long paths drain slowly at the end of a wave's run
+    // (cornell_smoke 130 vs 165 ms; cornell_box, closed as well, is level at best).  Instances stand for those here.
+    const bool whole_paths = c->scene.flat && c->n_perlin_tables == 0 && !c->has_groups && c->whole_paths_auto;
+    const int mode = c->pipeline >= 0 ? c->pipeline
+                                      : (whole_paths ? 3 : (c->info.n_nodes <= c->fused_node_limit ? 1 : c->deep_pipeline));
     // (flat scenes have no nodes to speak of and always fall on the fused side)
-    const bool fused = mode == 1;
+    const bool fused = mode == 1 || mode == 3;  // (the instrumented passes of mode 3 run the fused kernels)
     st.pipeline = (uint32_t)mode;
     if (n_owned && n_samples_total) {
         if ((rc = reserve_paths(c, n_owned * (uint64_t)n_samples_total, !fused))) return rc;
@@ -1084,6 +1095,17 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 uint32_t bps = (n_batch + rtk::BLOCK * rtk::NSHARD - 1) / (rtk::BLOCK * rtk::NSHARD);
                 st.batches++;
                 st.paths += n_batch;
+                if (mode == 3 && !c->count_visits) {
+                    // whole paths with regeneration: one launch, nothing queued
+                    {
+                        ScopedTimer tm(c, KS_PATHS);
+                        HIP_TRY(c, rtk::launch_paths(c->stream, tcfg, c->scene, rcst, batch, d_rad, d_stats, d_ovf));
+                    }
+                    st.bounce_launches++;
+                    ScopedTimer tm(c, KS_ACCUM);
+                    HIP_TRY(c, rtk::launch_accumulate(c->stream, (const float4*)c->d_radiance.p, batch, p->width, d_accum));
+                    continue;
+                }
                 if (mode != 0) {
                     HIP_TRY(c, hipMemsetAsync(q.counts, 0, 3 * rtk::NSHARD * sizeof(uint32_t), c->stream));
                 } else {
@@ -1159,13 +1181,14 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     }
     if (c->profile) {
-        double ms[KS_COUNT] = {0, 0, 0, 0, 0, 0};
+        double ms[KS_COUNT] = {0, 0, 0, 0, 0, 0, 0};
         for (auto& u : c->ev_used) {
             float t = 0;
             if (hipEventElapsedTime(&t, c->ev_pool[u.second.first], c->ev_pool[u.second.second]) == hipSuccess) ms[u.first] += t;
             if (u.first == KS_TRACE) st.trace_launches++;
             if (u.first == KS_SHADE) st.shade_launches++;
             if (u.first == KS_BOUNCE) st.bounce_kernel_launches++;
+            if (u.first == KS_PATHS) st.paths_launches++;
         }
         st.raygen_ms = ms[KS_RAYGEN];
         st.trace_ms = ms[KS_TRACE];
@@ -1173,6 +1196,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         st.accumulate_ms = ms[KS_ACCUM];
         st.bounce_ms = ms[KS_BOUNCE];
         st.tail_ms = ms[KS_TAIL];
+        st.paths_ms = ms[KS_PATHS];
     }
     st.render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = st;

@@ -75,6 +75,9 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& s
 hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc, PathState in,
                          Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
                          uint32_t* overflow_flag);
+// ---- whole paths with regeneration (flat scenes): one launch per batch, no queues --------------------------------
+hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc, const Batch& batch,
+                        float4* radiance, unsigned long long* stats, uint32_t* overflow_flag);
 
 hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, uint32_t width, float* accum_rgb);
 hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, bool sqrt_transfer, uint8_t* out);

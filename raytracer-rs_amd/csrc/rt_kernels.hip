@@ -5,6 +5,7 @@
 //   k_trace            closest hit of every live path          (bvh_node.rs:145-164 + shapes.rs intersect fns)
 //   k_shade            hit record, emitted, scatter, compaction (main.rs:44-63, materials.rs, texture.rs)
 //   k_finish           the last few live paths, each walked to its end by one lane (no queue, no launches)
+//   k_paths            whole paths per lane with regeneration: no queues at all (flat scenes)
 //   k_accumulate       per-pixel sum in sample order            (main.rs:478-481)
 //   k_resolve          quantise                                 (main.rs:307-313)
 //   k_intersect_batch  hit() path on caller-supplied rays
@@ -450,6 +451,60 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
     if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(stats + 8, (unsigned long long)rays);
 }
 
+// Whole paths, one launch: each wave owns a run of the batch's path slots; a lane generates a camera ray, follows
+// the path bounce by bounce in registers (the ray_color loop, main.rs:44-63) and, when the path has ended, takes
+// the next slot of the run ("path regeneration": dead lanes wait until at least REGEN of them can generate their
+// camera rays together).  Nothing but the final radiance leaves the chip: no path queues, no compaction barriers,
+// no launch per bounce.  That only pays where every lane of a wave does the same work per bounce -- scenes traced
+// flat; through a tree the lanes' walks diverge and the queue-based kernels, which re-pack rays between the walk
+// and the shading, stay ahead.  Draws are keyed by (stream, bounce): the image is the one the other pipelines give.
+template <bool GROUPS>
+__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : 5))) void k_paths(
+    Scene S, rtk::RenderConst rc, rtk::Batch batch, float4* __restrict__ radiance, unsigned long long* stats,
+    uint32_t* overflow_flag, uint32_t REGEN) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
+    const Stack stk{stack + threadIdx.x, S.stack_cap, nullptr, 0u};
+    const LdsTables L = stage_tables(S, stack);
+    const uint32_t n = batch.npix * batch.n_samples;
+    const uint32_t nw = gridDim.x * (rtk::BLOCK / 64u), wi = blockIdx.x * (rtk::BLOCK / 64u) + (threadIdx.x >> 6);
+    const uint32_t per = (((n + nw - 1u) / nw) + 63u) & ~63u;
+    uint32_t next = __builtin_amdgcn_readfirstlane(wi * per);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(next + per < n ? next + per : n);
+    bool have = false;
+    PathRegs p;
+    p.o = p.d = p.T = mk3(0.0f, 0.0f, 0.0f);
+    p.time = 0.0f;
+    p.k0 = p.k1 = p.slot = 0u;
+    uint32_t bounce = 0, rays = 0;
+    if (wi * per < n) {
+        for (;;) {
+            const unsigned long long idle = __ballot(!have);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (n_idle == 64u && next >= end) break;
+            if (next < end && (n_idle >= REGEN || n_idle == 64u)) {
+                const uint32_t mine = next + lane_prefix(idle);
+                next += n_idle;
+                if (!have && mine < end) {
+                    camera_path(rc, batch, mine, p);
+                    bounce = 0;
+                    have = true;
+                }
+            }
+            if (have) {
+                Hit h;
+                trace_ray<rtk::BLOCK, GROUPS, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk, overflow_flag, nullptr);
+                rays++;
+                if (shade_path(S, L, rc, p, h, bounce, radiance))
+                    bounce++;
+                else
+                    have = false;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(stats, (unsigned long long)rays);
+}
+
 // accum[pixel] += radiance of each sample, in sample order (main.rs:478: reduce(|c, src| c + src))
 __global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restrict__ radiance, rtk::Batch batch, uint32_t width,
                                                             float* __restrict__ accum_rgb) {
@@ -705,6 +760,31 @@ hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
         hipLaunchKernelGGL((k_finish<true>), grid, block, smem, s, scene, rc, in, q, bounce, radiance, stats, overflow_flag);
     else
         hipLaunchKernelGGL((k_finish<false>), grid, block, smem, s, scene, rc, in, q, bounce, radiance, stats, overflow_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, const Batch& batch,
+                        float4* radiance, unsigned long long* stats, uint32_t* overflow_flag) {
+    const size_t smem = stack_bytes(scene) + table_bytes(scene);
+    const unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
+    const uint32_t regen = (uint32_t)env_factor("RTAMD_REGEN", 8);
+    // Grid: runs of about 1536 path slots per wave, but never fewer blocks than fit on the chip at once.  Runs differ a
+    // lot in cost (sky next to glass) and the block scheduler balances them, so short runs are good -- until a run is
+    // so short that the lanes idling while its last paths drain (up to max_depth bounces) weigh against it.
+    static const unsigned long long run = 24ull * (unsigned long long)env_factor("RTAMD_PATHS_RUN", 64);  // units of 24 slots
+    const unsigned long long want = (n + (BLOCK / 64) * run - 1) / ((BLOCK / 64) * run);
+#define RT_PATHS(G)                                                                                                         \
+    do {                                                                                                                    \
+        const unsigned long long fit = resident_blocks((const void*)&k_paths<G>, smem);                                     \
+        const unsigned long long all = (n + BLOCK - 1) / BLOCK;                                                             \
+        const dim3 grid((uint32_t)std::max<unsigned long long>(1, std::min(all, std::min(std::max(want, fit), 1ull << 20)))); \
+        hipLaunchKernelGGL((k_paths<G>), grid, dim3(BLOCK), smem, s, scene, rc, batch, radiance, stats, overflow_flag, regen); \
+    } while (0)
+    if (cfg.has_groups)
+        RT_PATHS(true);
+    else
+        RT_PATHS(false);
+#undef RT_PATHS
     return hipGetLastError();
 }
 

@@ -281,7 +281,7 @@ def test_rank_split_sample_split_and_batch_size_change_no_bit(gpu_ctx):
     small.close()
 
 
-@pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "two_perlin_spheres"])
+@pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "two_perlin_spheres", "earth", "cornell_box"])
 def test_fused_and_split_pipelines_give_the_same_bits(name):
     w, h, spp = 150, 100, 5
     ctx = rtamd.Context(0)
@@ -289,14 +289,15 @@ def test_fused_and_split_pipelines_give_the_same_bits(name):
     ctx.load_scene(name, seed=1)
     cam = ctx.preset_camera(w / h)
     out = {}
-    for pipe in (0, 1, 2):  # split, fused, hybrid (fused camera rays, split scattered rays)
+    for pipe in (0, 1, 2, 3):  # split, fused, hybrid (fused camera rays, split scattered rays), whole paths
         ctx.set_pipeline(pipe)
         img, st = ctx.render(w, h, cam, spp, seed=9)
         assert st["pipeline"] == pipe
         out[pipe] = (img, st["rays"])
     ctx.close()
-    assert out[0][1] == out[1][1] == out[2][1]
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][0], out[2][0])
+    assert out[0][1] == out[1][1] == out[2][1] == out[3][1]
+    for pipe in (1, 2, 3):
+        assert np.array_equal(out[0][0], out[pipe][0])
 
 
 @pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "earth"])
