@@ -208,9 +208,12 @@ def main():
     for f in frames:
         f.ctx.profile(events=not args.no_profile)
         # set-up, not work: path queues allocated, pixel list uploaded and kernels loaded before the timed region,
-        # whatever --warmup says (one 1-spp pass of this rank's tiles; the frame is rendered again from zero)
-        f.ctx.reserve(len(rtamd.owned_pixels(f.w, f.h, f.tile, rank, world)) * spp)
-        f.render(spp=1, exchange=False)
+        # whatever --warmup says (one untimed pass of this rank's tiles; every step renders the frame again from zero).
+        # Full-size unless the frame is huge, so that a kernel-trace average over the whole process compares with
+        # the per-launch times of the timed steps.
+        n_mine = len(rtamd.owned_pixels(f.w, f.h, f.tile, rank, world))
+        f.ctx.reserve(n_mine * spp)
+        f.render(spp=spp if n_mine * spp <= (1 << 30) else 1, exchange=False)
     if world > 1 and args.backend == "nccl":
         # first collective builds the RCCL communicator: keep that out of the timed steps as well
         torch.distributed.all_reduce(torch.zeros(1, device=f"cuda:{local_rank}"))
@@ -255,8 +258,9 @@ def main():
             shade_ms = sum(st["shade_ms"] for s in stats for st in s)
             bounce_ms = sum(st["bounce_ms"] for s in stats for st in s)
             tail_ms = sum(st["tail_ms"] for s in stats for st in s)
+            paths_ms = sum(st["paths_ms"] for s in stats for st in s)
             # per-ray node fetches / primitive tests of this workload: one instrumented pass at 1 spp (untimed)
-            tr_bytes = sh_bytes = bo_bytes = 0.0
+            tr_bytes = sh_bytes = bo_bytes = pa_bytes = pa_must = 0.0
             for f, st_frame in zip(frames, zip(*stats)):
                 f.ctx.profile(events=False, count_visits=True)
                 st = f.render(spp=1, exchange=False)  # rank 0 alone: no collective here
@@ -267,7 +271,17 @@ def main():
                 f_rays = sum(s["rays"] - s["tail_rays"] for s in st_frame)
                 f_paths = sum(s["paths"] for s in st_frame)
                 alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
-                mode = st_frame[0]["pipeline"]  # 0 split, 1 fused, 2 hybrid: camera rays fused, scattered rays split
+                mode = st_frame[0]["pipeline"]  # 0 split, 1 fused, 2 hybrid: camera rays fused, scattered rays split, 3 whole paths
+                if mode == 3:
+                    # k_paths keeps a path's state in registers from bounce to bounce.  It is charged the per-ray figure of
+                    # the wavefront formulation all the same (state in + state out per bounce, as the metric's definition
+                    # has it), so that its rate compares with the per-bounce kernels'; what it really moves is `traffic`.
+                    primary = f_paths / max(f_rays, 1)
+                    pa_bytes += f_rays * bounce_bytes_per_ray(f.info, primary, alive, nodes_pr, prims_pr)
+                    pa_bytes += scene_bytes_per_launch(f.info) * sum(s["paths_launches"] for s in st_frame)
+                    # what k_paths itself has to move: a pixel index in and a radiance out per path, the scene once per XCD
+                    pa_must += f_paths * (4.0 + 16.0) + scene_bytes_per_launch(f.info) * sum(s["paths_launches"] for s in st_frame)
+                    continue
                 fused_rays = f_rays if mode == 1 else (f_paths if mode == 2 else 0)
                 split_rays = f_rays - fused_rays
                 if fused_rays:
@@ -281,8 +295,10 @@ def main():
             n_tr = sum(st["trace_launches"] for s in stats for st in s)
             n_sh = sum(st["shade_launches"] for s in stats for st in s)
             n_bo = sum(st["bounce_kernel_launches"] for s in stats for st in s)
+            n_pa = sum(st["paths_launches"] for s in stats for st in s)
             kernel, ms, nbytes, nl = max([("k_trace", trace_ms, tr_bytes, n_tr), ("k_shade", shade_ms, sh_bytes, n_sh),
-                                          ("k_bounce", bounce_ms, bo_bytes, n_bo)], key=lambda k: k[1])
+                                          ("k_bounce", bounce_ms, bo_bytes, n_bo), ("k_paths", paths_ms, pa_bytes, n_pa)],
+                                         key=lambda k: k[1])
             achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             traffic = measured_traffic(args.workload, kernel) if not (args.spp or args.width) else None
             roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS,
@@ -295,7 +311,14 @@ def main():
                     # path-state stream (plus one scene read per XCD and launch) is charged to HBM
                     "scene_resident_in_l2": all(f.info["device_bytes"] <= L2_PER_XCD for f in frames),
                     "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
-                    "bounce_ms_per_step": round(bounce_ms / args.steps, 3), "tail_ms_per_step": round(tail_ms / args.steps, 3)}
+                    "bounce_ms_per_step": round(bounce_ms / args.steps, 3), "tail_ms_per_step": round(tail_ms / args.steps, 3),
+                    "paths_ms_per_step": round(paths_ms / args.steps, 3)}
+            if kernel == "k_paths":
+                roof["note"] = ("k_paths follows whole paths in registers: the state bytes charged per bounce are those of the "
+                                "wavefront formulation and never reach HBM here (see traffic); own_bytes_* count only what this "
+                                "kernel must move -- it is bound by VALU issue, not by HBM")
+                roof["own_bytes_per_launch"] = round(pa_must / max(nl, 1), 1)
+                roof["own_bytes_frac"] = round(pa_must / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5)
             if achieved > PEAK_HBM_GBPS:
                 # only for scenes beyond L2 (64 B per node fetch charged to HBM): every ray walks the same upper
                 # levels of the tree, which L2 and the 256 MB MALL serve, so the algorithmic figure can exceed what HBM
