@@ -777,7 +777,9 @@ hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
     do {                                                                                                                    \
         const unsigned long long fit = resident_blocks((const void*)&k_paths<G>, smem);                                     \
         const unsigned long long all = (n + BLOCK - 1) / BLOCK;                                                             \
-        const dim3 grid((uint32_t)std::max<unsigned long long>(1, std::min(all, std::min(std::max(want, fit), 1ull << 20)))); \
+        /* small batches: 16 rounds of blocks if that leaves runs of 512 slots, for balance */                              \
+        const unsigned long long small = std::min(16 * fit, (n + (BLOCK / 64) * 512ull - 1) / ((BLOCK / 64) * 512ull));     \
+        const dim3 grid((uint32_t)std::max<unsigned long long>(1, std::min(all, std::min(std::max({want, fit, small}), 1ull << 20)))); \
         hipLaunchKernelGGL((k_paths<G>), grid, dim3(BLOCK), smem, s, scene, rc, batch, radiance, stats, overflow_flag, regen); \
     } while (0)
     if (cfg.has_groups)
