@@ -185,3 +185,46 @@ def test_empty_world_renders_the_background():
         acc = acc + bg
     assert st["rays"] == st["paths"] == 33 * 22 * 5 and np.all(img == acc)
     ctx.close()
+
+
+# ---- random raw scenes through every pipeline ------------------------------------------------------------------
+@pytest.mark.parametrize("seed,n_sph,n_rect", [(1, 5, 3), (2, 20, 12), (3, 400, 150), (4, 3000, 0)])
+def test_random_raw_scenes_agree_across_pipelines_and_builders(seed, n_sph, n_rect):
+    """Random worlds sent through rt_scene_set_* (spheres of all five material kinds, some moving, rects of all three
+    axes): split, fused, hybrid and whole-path pipelines, with and without the tail kernel, host- and device-built
+    trees must all give one image and one ray count."""
+    import ctypes as C
+    rng = np.random.default_rng(seed)
+    texs = [rtamd.rt_texture(kind=0, color=(C.c_float * 3)(*rng.uniform(0.2, 0.9, 3))) for _ in range(4)]
+    texs.append(rtamd.rt_texture(kind=1, odd=0, even=1))  # checker of two solids
+    mats = [rtamd.rt_material(kind=0, tex=0), rtamd.rt_material(kind=0, tex=4),
+            rtamd.rt_material(kind=1, albedo=(C.c_float * 3)(0.8, 0.7, 0.6), fuzz=0.3),
+            rtamd.rt_material(kind=2, ior=1.5), rtamd.rt_material(kind=3, tex=2), rtamd.rt_material(kind=4, tex=3)]
+    c0r = np.concatenate([rng.uniform(-8, 8, (n_sph, 3)), rng.uniform(0.2, 1.2, (n_sph, 1))], 1).astype(np.float32)
+    sph = dict(c0r=c0r, c1=(c0r[:, :3] + rng.uniform(-0.5, 0.5, (n_sph, 3))).astype(np.float32),
+               t01=np.tile(np.float32([[0.0, 1.0]]), (n_sph, 1)), moving=(rng.uniform(0, 1, n_sph) < 0.3).astype(np.uint8),
+               mat=rng.integers(0, len(mats), n_sph).astype(np.uint32), id=np.arange(n_sph, dtype=np.uint32))
+    rects = None
+    if n_rect:
+        lo = rng.uniform(-8, 6, (n_rect, 2))
+        rects = dict(axis=rng.integers(0, 3, n_rect).astype(np.uint8), k=rng.uniform(-8, 8, n_rect).astype(np.float32),
+                     bounds=np.concatenate([lo, lo + rng.uniform(0.5, 3.0, (n_rect, 2))], 1).astype(np.float32),
+                     mat=rng.integers(0, len(mats), n_rect).astype(np.uint32), id=np.arange(n_sph, n_sph + n_rect, dtype=np.uint32))
+    cam = rtamd.camera_new((0, 2, -25), (0, 0, 0), (0, 1, 0), 0.7, 1.5, 0.2, 25.0, 0.0, 1.0)
+    w, h, spp = 150, 100, 4
+    out = []
+    for builder in (0, 1):
+        ctx = rtamd.Context(0)
+        ctx.set_builder(builder)
+        ctx.set_scene(spheres=sph, rects=rects, materials=mats, textures=texs)
+        for pipe in (0, 1, 2, 3):
+            for tail in (0, 1 << 30):
+                ctx.set_pipeline(pipe)
+                ctx.set_tail_paths(tail)
+                img, st = ctx.render(w, h, cam, spp, depth=20, seed=seed, background=np.float32([0.6, 0.7, 0.9]))
+                assert np.isfinite(img).all()
+                out.append((img, st["rays"]))
+        ctx.close()
+    assert out[0][1] > w * h * spp  # something was hit
+    for img, rays in out[1:]:
+        assert rays == out[0][1] and np.array_equal(img, out[0][0])
