@@ -724,7 +724,10 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         if ((rc = ensure(c, c->d_prims, ((size_t)base + nw_all) * sizeof(rtd::Prim)))) return rc;
         if (base) HIP_TRY(c, hipMemcpy(c->d_prims.p, prims.data(), (size_t)base * sizeof(rtd::Prim), hipMemcpyHostToDevice));
         DevBuf unsorted;
-        if ((rc = upload(c, unsorted, wprims.data(), (size_t)nw * sizeof(rtd::Prim)))) return rc;
+        if ((rc = upload(c, unsorted, wprims.data(), (size_t)nw * sizeof(rtd::Prim)))) {
+            unsorted.release();
+            return rc;
+        }
         rtl::Workspace ws;
         float wlo[3], whi[3];
         hipError_t e = rtl::sort_world(c->stream, ws, (const rtd::Prim*)unsorted.p, (const rtd::Moving*)c->d_moving.p, nw, shutter_t0,
