@@ -27,6 +27,9 @@
 
 namespace {
 
+#ifndef PATHS_WAVES
+#define PATHS_WAVES 6
+#endif
 #ifndef BOUNCE_WAVES
 #define BOUNCE_WAVES 5
 #endif
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
 // flat; through a tree the lanes' walks diverge and the queue-based kernels, which re-pack rays between the walk
 // and the shading, stay ahead.  Draws are keyed by (stream, bounce): the image is the one the other pipelines give.
 template <bool GROUPS>
-__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : 5))) void k_paths(
+__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : PATHS_WAVES))) void k_paths(
     Scene S, rtk::RenderConst rc, rtk::Batch batch, float4* __restrict__ radiance, unsigned long long* stats,
     uint32_t* overflow_flag, uint32_t REGEN) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // S.stack_cap entries per lane, [entry][lane]
