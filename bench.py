@@ -296,15 +296,19 @@ def main():
             n_sh = sum(st["shade_launches"] for s in stats for st in s)
             n_bo = sum(st["bounce_kernel_launches"] for s in stats for st in s)
             n_pa = sum(st["paths_launches"] for s in stats for st in s)
-            kernel, ms, nbytes, nl = max([("k_trace", trace_ms, tr_bytes, n_tr), ("k_shade", shade_ms, sh_bytes, n_sh),
-                                          ("k_bounce", bounce_ms, bo_bytes, n_bo), ("k_paths", paths_ms, pa_bytes, n_pa)],
-                                         key=lambda k: k[1])
+            cands = [("k_trace", trace_ms, tr_bytes, n_tr), ("k_shade", shade_ms, sh_bytes, n_sh),
+                     ("k_bounce", bounce_ms, bo_bytes, n_bo), ("k_paths", paths_ms, pa_bytes, n_pa)]
+            kernel, ms, nbytes, nl = max(cands, key=lambda k: k[1])
             achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            traffic = measured_traffic(args.workload, kernel) if not (args.spp or args.width) else None
+
+            def traffic_per_launch(name, launches):
+                t = measured_traffic(args.workload, name) if not (args.spp or args.width) else None
+                return (round(t[0] * args.steps / max(launches, 1), 1), t[1]) if t else (None, None)
+
+            traffic = traffic_per_launch(kernel, nl)
             roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS,
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 5),
-                    "traffic": round(traffic[0] * args.steps / max(nl, 1), 1) if traffic else None,
-                    "traffic_source": traffic[1] if traffic else None,
+                    "traffic": traffic[0], "traffic_source": traffic[1],
                     "launches": int(nl), "avg_launch_ms": round(ms / max(nl, 1), 5),
                     "algorithmic_bytes_per_launch": round(nbytes / max(nl, 1), 1),
                     # True: the scene fits an XCD's L2, so per-ray node/primitive fetches are cache hits and only the
@@ -313,6 +317,19 @@ def main():
                     "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
                     "bounce_ms_per_step": round(bounce_ms / args.steps, 3), "tail_ms_per_step": round(tail_ms / args.steps, 3),
                     "paths_ms_per_step": round(paths_ms / args.steps, 3)}
+            # the other kernels that take a real share of the step, in the same terms (when two kernels take about the
+            # same time, which of them is "dominant" flips from run to run)
+            others = []
+            for k_name, k_ms, k_bytes, k_nl in cands:
+                if k_name != kernel and k_ms > 0.15 * ms and k_nl:
+                    k_ach = k_bytes / (k_ms * 1e-3) / 1e9
+                    k_tr = traffic_per_launch(k_name, k_nl)
+                    others.append({"kernel": k_name, "achieved": round(k_ach, 2), "frac": round(k_ach / PEAK_HBM_GBPS, 5),
+                                   "launches": int(k_nl), "avg_launch_ms": round(k_ms / k_nl, 5),
+                                   "algorithmic_bytes_per_launch": round(k_bytes / k_nl, 1), "traffic": k_tr[0],
+                                   "traffic_source": k_tr[1]})
+            if others:
+                roof["other_kernels"] = others
             if kernel == "k_paths":
                 roof["note"] = ("k_paths follows whole paths in registers: the state bytes charged per bounce are those of the "
                                 "wavefront formulation and never reach HBM here (see traffic); own_bytes_* count only what this "
