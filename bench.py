@@ -57,13 +57,17 @@ def log(*a):
 class Frame:
     """One scene of the workload on this rank: context, camera, accumulation buffer, gather plan."""
 
-    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=32, gather_on_cpu=False):
+    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=32, gather_on_cpu=False, own_stream=False):
         self.name, self.w, self.spp = name, width, spp
         self.h = rtamd.image_height(width, aspect)
         self.rank, self.world = rank, world
         self.ctx = rtamd.Context(device)
         self.info = self.ctx.load_scene(name, seed=1, n_synth=n_synth)
-        self.ctx.use_torch_stream()
+        # own_stream: the context keeps its own HIP stream, so that several frames can render at once (render() then
+        # has to be called with the torch stream idle: the accumulation buffer is zeroed on that one)
+        self.own_stream = own_stream
+        if not own_stream:
+            self.ctx.use_torch_stream()
         self.cam = self.ctx.preset_camera(aspect)
         self.accum = torch.zeros((self.h, self.w, 3), dtype=torch.float32, device=f"cuda:{device}")
         self.tile = tile
@@ -71,13 +75,26 @@ class Frame:
         self.gather_dev = torch.device("cpu") if gather_on_cpu else self.accum.device
         self.gather = TileGather(self.w, self.h, rank, world, self.gather_dev, tile) if world > 1 else None
 
-    def render(self, spp=None, exchange=True):
+    def clear(self):
         self.accum.zero_()
+
+    def trace(self, spp=None):
         _, st = self.ctx.render(self.w, self.h, self.cam, spp or self.spp, depth=MAX_DEPTH, seed=1, accum=self.accum,
                                 tile_size=self.tile, rank=self.rank, nranks=self.world)
-        if self.gather is not None and exchange:
+        return st
+
+    def exchange(self):
+        if self.gather is not None:
             # framebuffer exchange: every rank owns disjoint tiles -> one all_gather of the packed tiles
             self.frame = self.gather.gather(self.accum.to(self.gather_dev))
+
+    def render(self, spp=None, exchange=True):
+        self.clear()
+        if self.own_stream:
+            torch.cuda.current_stream().synchronize()
+        st = self.trace(spp)
+        if exchange:
+            self.exchange()
         return st
 
     def image(self):
@@ -178,6 +195,9 @@ def main():
     ap.add_argument("--synth-n", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing (roofline becomes null)")
+    ap.add_argument("--frames-at-once", type=int, default=-1, choices=[-1, 0, 1],
+                    help="render the frames of a step concurrently, one HIP stream and host thread each (default: only "
+                         "when the step is split over several ranks, where one rank's share of a frame no longer fills the GPU)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (exchange staged through host memory, ranks may share a GPU) "
                          "only rehearses the multi-rank path on a box with fewer GPUs than ranks")
@@ -203,8 +223,18 @@ def main():
     frames_cfg, width, aspect, spp = WORKLOADS[args.workload]
     width = args.width or width
     spp = args.spp or spp
-    frames = [Frame(n, width, aspect, spp, rank, world, local_rank, args.synth_n, gather_on_cpu=args.backend == "gloo")
+    # A rank's share of a frame is small when the step is split N ways: the tail of every launch and the host round
+    # trips of one frame then leave the GPU partly idle.  The frames of a step are independent, so a rank renders them
+    # at once, each on its own stream from its own host thread.  With one rank every launch fills the GPU anyway and
+    # the frames run one after the other, which also keeps the per-kernel HIP-event times free of overlap.
+    at_once = len(frames_cfg) > 1 and (args.frames_at_once == 1 or (args.frames_at_once < 0 and world > 1))
+    frames = [Frame(n, width, aspect, spp, rank, world, local_rank, args.synth_n, gather_on_cpu=args.backend == "gloo",
+                    own_stream=at_once)
               for n in frames_cfg]
+    pool = None
+    if at_once:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=len(frames))
     for f in frames:
         f.ctx.profile(events=not args.no_profile)
         # set-up, not work: path queues allocated, pixel list uploaded and kernels loaded before the timed region,
@@ -224,7 +254,15 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        return [f.render() for f in frames]
+        if pool is None:
+            return [f.render() for f in frames]
+        for f in frames:
+            f.clear()
+        torch.cuda.current_stream().synchronize()  # the buffers are zero before any context's stream adds to them
+        st = list(pool.map(lambda f: f.trace(), frames))  # rt_render returns with its stream drained
+        for f in frames:
+            f.exchange()
+        return st
 
     for _ in range(args.warmup):
         step()
@@ -336,6 +374,10 @@ def main():
                                 "kernel must move -- it is bound by VALU issue, not by HBM")
                 roof["own_bytes_per_launch"] = round(pa_must / max(nl, 1), 1)
                 roof["own_bytes_frac"] = round(pa_must / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5)
+            if at_once:
+                # the frames share the GPU, so a kernel's HIP-event time includes the time it waited for the others'
+                # waves: the per-kernel figures of such a run are upper bounds of the time, lower bounds of the rate
+                roof["overlapped_streams"] = True
             if achieved > PEAK_HBM_GBPS:
                 # only for scenes beyond L2 (64 B per node fetch charged to HBM): every ray walks the same upper
                 # levels of the tree, which L2 and the 256 MB MALL serve, so the algorithmic figure can exceed what HBM
@@ -349,6 +391,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "frames": list(frames_cfg), "width": width, "height": frames[0].h,
                        "spp": spp, "max_depth": MAX_DEPTH, "tile_split": f"32x32 tiles round-robin over {world} rank(s)",
+                       "frames_at_once": bool(at_once),
                        "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps,
                        "sec_per_frame": round(elapsed / args.steps / len(frames), 5)},
             "roofline": roof,

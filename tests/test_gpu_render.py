@@ -300,6 +300,26 @@ def test_fused_and_split_pipelines_give_the_same_bits(name):
         assert np.array_equal(out[0][0], out[pipe][0])
 
 
+def test_contexts_render_concurrently_from_host_threads():
+    """Contexts are independent: three of them, each on its own HIP stream and driven by its own host thread, render
+    different scenes at the same time and give the images and ray counts that they give one after the other."""
+    from concurrent.futures import ThreadPoolExecutor
+    w, h, spp = 200, 120, 6
+    jobs = []
+    for name in ("two_spheres", "two_perlin_spheres", "final_scene"):
+        ctx = rtamd.Context(0)
+        ctx.load_scene(name, seed=1)
+        jobs.append((ctx, ctx.preset_camera(w / h)))
+    alone = [ctx.render(w, h, cam, spp, seed=21) for ctx, cam in jobs]
+    with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+        for _ in range(3):
+            together = list(pool.map(lambda j: j[0].render(w, h, j[1], spp, seed=21), jobs))
+            for (img_a, st_a), (img_t, st_t) in zip(alone, together):
+                assert st_a["rays"] == st_t["rays"] and np.array_equal(img_a, img_t)
+    for ctx, _ in jobs:
+        ctx.close()
+
+
 @pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "earth"])
 def test_tail_kernel_changes_no_bit(name):
     """The last live paths of a batch are walked to their end by one launch (k_finish) instead of one launch per
