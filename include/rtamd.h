@@ -134,6 +134,12 @@ int rt_scene_commit(rt_ctx* ctx, float shutter_t0, float shutter_t1);
  * primitives on, env RTAMD_GPU_BUILD_MIN), 0 = host, 1 = device (env RTAMD_BUILDER).  Every valid tree gives
  * the same hits; the builders differ in build time and in node visits per ray. */
 int rt_ctx_set_builder(rt_ctx* ctx, int builder);
+/* Children per inner node the kernels walk from the next rt_scene_commit on: 2 (default; 64-byte nodes holding both
+ * child boxes) or 4 (env RTAMD_BVH_WIDTH=4: the finished tree, whichever builder made it, is also written in a
+ * 128-byte four-child form -- the grandchildren of every node -- which halves the chain of dependent node fetches
+ * per ray).  The reference's tree is binary (bvh_node.rs:26-30); the width changes no hit.  A tree whose four-child
+ * walk could need more than 64 stack entries keeps the binary walk (rt_scene_info.bvh_width tells). */
+int rt_ctx_set_bvh_width(rt_ctx* ctx, int width);
 
 typedef struct rt_scene_info {
     uint64_t n_prims, n_nodes, n_groups, n_media;
@@ -143,7 +149,7 @@ typedef struct rt_scene_info {
     double build_seconds;  /* all of rt_scene_commit */
     double tree_seconds;   /* of which: the world-level tree (build + upload of nodes and primitives) */
     uint32_t builder;      /* 0 host, 1 device */
-    uint32_t reserved;
+    uint32_t bvh_width;    /* children per inner node the kernels walk: 2 or 4 */
 } rt_scene_info;
 int rt_scene_get_info(rt_ctx* ctx, rt_scene_info* out);
 /* Inspection (tests, tools): copies the committed tree to host memory.  nodes: n_nodes records of 64 bytes

@@ -87,6 +87,8 @@ struct rt_ctx {
     uint64_t fused_node_limit = 64;  // scenes with more BVH nodes than this take deep_pipeline
     int builder = -1;  // world-level BVH: -1 by size, 0 host (binned SAH), 1 device (linear BVH)
     uint64_t gpu_build_min = 1u << 18;  // builder -1: worlds with at least this many primitives are built on the device
+    int bvh_width = 2;  // children per inner node the kernels walk: 2, or 4 (four-child form made at commit)
+    DevBuf d_wide;
     uint64_t tail_paths = 256u << 10;  // a batch with at most this many live paths is finished by one k_finish launch
     rtk::SpillArea trace_spill;  // deep traversal-stack entries of k_trace (launch_trace grows it)
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
@@ -357,6 +359,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (getenv("RTAMD_TAIL_PATHS")) c->tail_paths = env_u32("RTAMD_TAIL_PATHS", 0);
     if (getenv("RTAMD_BUILDER")) c->builder = (int)std::min(env_u32("RTAMD_BUILDER", 0), 1u);
     if (getenv("RTAMD_GPU_BUILD_MIN")) c->gpu_build_min = env_u32("RTAMD_GPU_BUILD_MIN", 0);
+    if (getenv("RTAMD_BVH_WIDTH")) c->bvh_width = env_u32("RTAMD_BVH_WIDTH", 2) == 4 ? 4 : 2;
     *out = c;
     return RT_OK;
 }
@@ -365,7 +368,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->d_prims, &c->d_moving, &c->d_nodes, &c->d_groups, &c->d_mats, &c->d_texs, &c->d_perlin,
+    DevBuf* bufs[] = {&c->d_prims, &c->d_moving, &c->d_nodes, &c->d_wide, &c->d_groups, &c->d_mats, &c->d_texs, &c->d_perlin,
                       &c->d_images, &c->d_media, &c->d_hits, &c->d_radiance, &c->d_counts, &c->d_rays, &c->d_overflow, &c->d_pixels,
                       &c->d_accum};
     for (DevBuf* b : bufs) b->release();
@@ -400,6 +403,11 @@ int rt_ctx_set_pipeline(rt_ctx* c, int pipeline) {
 int rt_ctx_set_builder(rt_ctx* c, int builder) {
     if (!c || builder < -1 || builder > 1) return fail(c, RT_ERR_INVALID, "builder must be -1, 0 or 1");
     c->builder = builder;
+    return RT_OK;
+}
+int rt_ctx_set_bvh_width(rt_ctx* c, int width) {
+    if (!c || (width != 2 && width != 4)) return fail(c, RT_ERR_INVALID, "bvh width must be 2 or 4");
+    c->bvh_width = width;
     return RT_OK;
 }
 int rt_ctx_reserve(rt_ctx* c, uint64_t n_paths) {
@@ -785,6 +793,19 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
 
     uint32_t need = top_r.depth + lbvh_depth + (n_inst ? 1 + blas_depth : 0) + 1;
     if (need > 64) return fail(c, RT_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack");
+    // Four-child walk: a node covers two binary levels and leaves up to three entries behind.  The top level, the
+    // device-built world tree and the instances' trees are widened separately (each from its own root).
+    const uint32_t need_wide = 3u * ((top_r.depth + 1) / 2 + (lbvh_depth + 1) / 2 + (n_inst ? (blas_depth + 1) / 2 : 0)) + (n_inst ? 1 : 0) + 1;
+    const bool wide = c->bvh_width == 4 && !flat_ok && n_nodes_total > 0 && need_wide <= 64;
+    if (wide) {
+        need = need_wide;
+        if ((rc = ensure(c, c->d_wide, n_nodes_total * sizeof(rtd::WideNode)))) return rc;
+        hipError_t e = rtl::widen_tree(c->stream, (const rtd::Node*)c->d_nodes.p, (uint32_t)n_nodes_total, (rtd::WideNode*)c->d_wide.p);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(c, e, "four-child form of the BVH");
+    } else {
+        c->d_wide.release();
+    }
     c->stack_entries = (int)(flat_ok ? 1u : need);
     c->has_groups = ng > 0;
 
@@ -854,6 +875,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.prims = (const rtd::Prim*)c->d_prims.p;
     S.moving = (const rtd::Moving*)c->d_moving.p;
     S.nodes = (const rtd::Node*)c->d_nodes.p;
+    S.wide = wide ? (const rtd::WideNode*)c->d_wide.p : nullptr;
     S.groups = (const rtd::Group*)c->d_groups.p;
     S.mats = (const rtd::Material*)c->d_mats.p;
     S.texs = (const rtd::Texture*)c->d_texs.p;
@@ -878,12 +900,13 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     c->info.n_prims = n_prims_total;
     c->info.n_nodes = n_nodes_total;
     c->info.builder = device_build ? 1u : 0u;
+    c->info.bvh_width = wide ? 4u : 2u;
     c->info.n_groups = ng;
     c->info.n_media = n_media;
     c->info.max_depth = need;
     c->info.stack_entries = (uint32_t)c->stack_entries;
     c->info.device_bytes = n_prims_total * sizeof(rtd::Prim) + moving.size() * sizeof(rtd::Moving) +
-                           n_nodes_total * sizeof(rtd::Node) + dgroups.size() * sizeof(rtd::Group) +
+                           n_nodes_total * (sizeof(rtd::Node) + (wide ? sizeof(rtd::WideNode) : 0)) + dgroups.size() * sizeof(rtd::Group) +
                            c->mats.size() * sizeof(rt_material) + c->texs.size() * sizeof(rt_texture) +
                            ptab.size() * sizeof(rtd::PerlinTable) + image_bytes;
     c->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();

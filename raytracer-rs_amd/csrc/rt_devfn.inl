@@ -427,8 +427,72 @@ DEV void walk_begin(const Scene& S, Walk& w, f3 wo, f3 wd, float tmax) {
 DEV bool walk_done(const Walk& w) { return w.cur == REF_EMPTY; }
 // Walks inner nodes only (at most max_steps of them), until cur is a leaf, an instance, a sentinel or empty.
 // Near child first; a box is entered only if it can still hold a hit at or before the closest one.
+// Orders two (entry distance, reference) pairs, nearer first.
+DEV void near_first(float& ka, uint32_t& ra, float& kb, uint32_t& rb) {
+    const bool swap = kb < ka;
+    const float k = swap ? kb : ka;
+    const uint32_t r = swap ? rb : ra;
+    kb = swap ? ka : kb;
+    rb = swap ? ra : rb;
+    ka = k;
+    ra = r;
+}
+// The same walk over four-child nodes: one 128-byte fetch decides about four boxes, which halves the chain of
+// dependent fetches per ray.  The children that are hit are entered nearest first; the others wait on the stack,
+// the farthest at the bottom.  Every valid tree gives the same closest hit, so the result equals the binary walk's.
+template <int STRIDE, bool COUNT>
+DEV void walk_inner_wide(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt,
+                         int max_steps) {
+    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) {
+        const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
+        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
+        if (COUNT) cnt->nodes++;
+        float k0, k1, k2, k3;
+        uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z), r3 = __float_as_uint(q6.w);
+        const bool h0 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), w.o, w.inv, tmin, w.best.t, k0) && r0 != REF_EMPTY;
+        const bool h1 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), w.o, w.inv, tmin, w.best.t, k1) && r1 != REF_EMPTY;
+        const bool h2 = slab(mk3(q3.x, q3.y, q3.z), mk3(q3.w, q4.x, q4.y), w.o, w.inv, tmin, w.best.t, k2) && r2 != REF_EMPTY;
+        const bool h3 = slab(mk3(q4.z, q4.w, q5.x), mk3(q5.y, q5.z, q5.w), w.o, w.inv, tmin, w.best.t, k3) && r3 != REF_EMPTY;
+        // a box that is hit has a finite entry distance (or -inf), so +inf sorts the misses behind every hit
+        k0 = h0 ? k0 : INF_F;
+        k1 = h1 ? k1 : INF_F;
+        k2 = h2 ? k2 : INF_F;
+        k3 = h3 ? k3 : INF_F;
+        r0 = h0 ? r0 : REF_EMPTY;
+        r1 = h1 ? r1 : REF_EMPTY;
+        r2 = h2 ? r2 : REF_EMPTY;
+        r3 = h3 ? r3 : REF_EMPTY;
+        near_first(k0, r0, k1, r1);
+        near_first(k2, r2, k3, r3);
+        near_first(k0, r0, k2, r2);
+        near_first(k1, r1, k3, r3);
+        near_first(k1, r1, k2, r2);
+        if (r0 != REF_EMPTY) {
+            w.cur = r0;
+            const int n_push = (r1 != REF_EMPTY) + (r2 != REF_EMPTY) + (r3 != REF_EMPTY);
+            if (n_push) {
+                if (w.sp + n_push <= (int)S.stack_cap) {
+                    if (r3 != REF_EMPTY) stack_put<STRIDE>(stk, w.sp++, r3);
+                    if (r2 != REF_EMPTY) stack_put<STRIDE>(stk, w.sp++, r2);
+                    stack_put<STRIDE>(stk, w.sp++, r1);
+                } else {
+                    *overflow_flag = 1u;
+                }
+            }
+        } else if (w.sp > 0) {
+            w.sp--;
+            w.cur = stack_get<STRIDE>(stk, w.sp);
+        } else {
+            w.cur = REF_EMPTY;
+        }
+    }
+}
 template <int STRIDE, bool COUNT>
 DEV void walk_inner(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
+    if (S.wide) {  // (the same in every lane)
+        walk_inner_wide<STRIDE, COUNT>(S, w, tmin, stk, overflow_flag, cnt, max_steps);
+        return;
+    }
     for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) {
         const float4* np = reinterpret_cast<const float4*>(S.nodes + w.cur);
         float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];

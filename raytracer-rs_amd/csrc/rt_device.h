@@ -4,6 +4,7 @@
 //   prims[]   32-B records in BVH leaf order (sphere: centre+radius, rect: plane+bounds),
 //   moving[]  32-B side records for moving spheres (second centre, shutter times),
 //   nodes[]   64-B inner nodes holding BOTH child boxes and both child references,
+//   wide[]    optional 128-B four-child form of the same nodes,
 //   groups[]  instance / medium descriptors (3x4 transforms, medium density, root reference),
 //   mats[], texs[], perlin[], images[].
 #pragma once
@@ -50,6 +51,17 @@ struct alignas(64) Node {
     uint32_t pad[2];
 };
 static_assert(sizeof(Node) == 64, "Node must be 64 B");
+
+// Four-wide form of the same tree: wide[i] holds the GRANDchildren of binary node i (a child that is not an
+// inner node keeps its slot, its partner slot is empty).  A walk that starts at the root only ever lands on
+// binary nodes of even depth, so the entries of odd depth are never read; keeping one entry per binary node
+// makes the conversion a map over the node array (no compaction, same indices, same references).
+struct alignas(128) WideNode {
+    float box[4][6];  // slot s: lo.xyz, hi.xyz
+    uint32_t c[4];    // REF_EMPTY: unused slot
+    uint32_t pad[4];
+};
+static_assert(sizeof(WideNode) == 128, "WideNode must be 128 B");
 
 struct alignas(16) Group {
     float m[12];     // object -> world, rows
@@ -108,6 +120,7 @@ struct Scene {
     const Prim* prims;
     const Moving* moving;
     const Node* nodes;
+    const WideNode* wide;  // non-null: inner nodes are walked four children at a time
     const Group* groups;
     const Material* mats;
     const Texture* texs;

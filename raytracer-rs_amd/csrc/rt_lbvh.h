@@ -42,4 +42,8 @@ hipError_t build_tree(hipStream_t s, Workspace& w, const rtd::Prim* sorted, cons
                       float shutter_t0, float shutter_t1, uint32_t prim_base, rtd::Node* nodes, uint32_t node_base,
                       uint32_t* depth);
 
+// Four-child form of a finished tree of n binary nodes (host- or device-built, instances' subtrees included):
+// wide[i] holds the grandchildren of nodes[i].  Both arrays on the device; asynchronous on s.
+hipError_t widen_tree(hipStream_t s, const rtd::Node* nodes, uint32_t n, rtd::WideNode* wide);
+
 }  // namespace rtl

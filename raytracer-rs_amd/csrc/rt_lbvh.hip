@@ -7,6 +7,7 @@
 //   k_hierarchy  one thread per inner node: its key range and split by binary search on common prefixes
 //   k_fit        one thread per leaf: climbs to the root; the second thread to arrive at a node carries on
 //   k_depth      one thread per leaf: inner nodes on its path to the root -> atomic max
+//   k_widen      one thread per inner node: the four-child form of the finished tree (any builder's)
 //
 // All of it is HBM-bound streaming work except the sort; nothing here decides a hit (boxes only cull), but the
 // box arithmetic is kept identical to the host builder's (-ffp-contract=off) so both builders cull alike.
@@ -261,6 +262,44 @@ __global__ __launch_bounds__(BLOCK) void k_depth(uint32_t n, const uint32_t* par
     if ((threadIdx.x & 63u) == 0 && d) atomicMax(depth, d);
 }
 
+// Four-child form of binary node i: the children of its inner children, or the child itself where that is a
+// leaf, an instance or empty.  One thread per node; a map over the array (the entries of odd tree depth are
+// never reached by a walk from the root, they are written all the same).
+__global__ __launch_bounds__(BLOCK) void k_widen(uint32_t n, const rtd::Node* nodes, rtd::WideNode* wide) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const rtd::Node b = nodes[i];
+    rtd::WideNode out;
+    for (int k = 0; k < 2; k++) {
+        const uint32_t ref = k ? b.c1 : b.c0;
+        const float* lo = k ? b.lo1 : b.lo0;
+        const float* hi = k ? b.hi1 : b.hi0;
+        int s = 2 * k;
+        if (ref != rtd::REF_EMPTY && (ref >> 30) == rtd::REF_INNER && ref < n) {
+            const rtd::Node g = nodes[ref];
+            for (int a = 0; a < 3; a++) {
+                out.box[s][a] = g.lo0[a];
+                out.box[s][3 + a] = g.hi0[a];
+                out.box[s + 1][a] = g.lo1[a];
+                out.box[s + 1][3 + a] = g.hi1[a];
+            }
+            out.c[s] = g.c0;
+            out.c[s + 1] = g.c1;
+        } else {
+            for (int a = 0; a < 3; a++) {
+                out.box[s][a] = lo[a];
+                out.box[s][3 + a] = hi[a];
+                out.box[s + 1][a] = 0.0f;
+                out.box[s + 1][3 + a] = 0.0f;
+            }
+            out.c[s] = ref;
+            out.c[s + 1] = rtd::REF_EMPTY;
+        }
+    }
+    for (int a = 0; a < 4; a++) out.pad[a] = 0u;
+    wide[i] = out;
+}
+
 hipError_t dev_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16); }
 inline int grid_for(uint64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 
@@ -343,6 +382,12 @@ hipError_t build_tree(hipStream_t s, Workspace& w, const rtd::Prim* sorted, cons
     RTL_TRY(hipStreamSynchronize(s));
     *depth = d;
     return hipSuccess;
+}
+
+hipError_t widen_tree(hipStream_t s, const rtd::Node* nodes, uint32_t n, rtd::WideNode* wide) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_widen, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, nodes, wide);
+    return hipGetLastError();
 }
 
 }  // namespace rtl

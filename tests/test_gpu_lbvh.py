@@ -109,6 +109,56 @@ def test_device_and_host_trees_give_the_same_bits(name, n_synth, w):
         assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
 
 
+@pytest.mark.parametrize("name,n_synth,w,builder", [("synth_spheres", 60_000, 320, 1), ("synth_spheres", 3000, 240, 0),
+                                                    ("random_world", 0, 200, 0), ("random_world", 0, 200, 1),
+                                                    ("final_scene", 0, 160, 0), ("final_scene", 0, 160, 1)])
+def test_four_child_walk_gives_the_same_bits(name, n_synth, w, builder):
+    """The kernels walk the tree two children at a time, or four (the grandchildren of every node in one 128-byte
+    record).  Hits of a ray batch and images of every tree-walking pipeline must be the same; only the number of
+    node fetches may differ (about half)."""
+    h = w * 3 // 4
+    out = []
+    for width in (2, 4):
+        rng = np.random.default_rng(9)
+        ctx = rtamd.Context(0)
+        ctx.set_tail_paths(2048)
+        ctx.set_builder(builder)
+        ctx.set_bvh_width(width)
+        info = ctx.load_scene(name, seed=2, n_synth=n_synth)
+        assert info["bvh_width"] == width and info["builder"] == builder
+        cam = ctx.preset_camera(w / h)
+        o = np.array(cam.as_array()[:3], np.float32)
+        n = 20000
+        target = np.zeros(3, np.float32) if name != "final_scene" else np.array([278, 278, 0], np.float32)
+        d = (target - o)[None, :] + rng.normal(0, 0.25 * np.linalg.norm(target - o), (n, 3)).astype(np.float32)
+        rays = np.concatenate([np.repeat(o[:, None], n, 1), d.T.astype(np.float32), rng.uniform(0, 1, (1, n)).astype(np.float32)])
+        hit = ctx.intersect(rays.astype(np.float32), seed=3)
+        res = [hit["prim"], hit["inst"], hit["t"], hit["normal"], hit["front"]]
+        for pipe in (0, 1, 2):
+            ctx.set_pipeline(pipe)
+            img, st = ctx.render(w, h, cam, 3, seed=7)
+            res += [img, np.array([st["rays"]])]
+        ctx.set_pipeline(0)
+        ctx.profile(events=False, count_visits=True)
+        _, st = ctx.render(w, h, cam, 1, seed=7)
+        visits = st["node_visits"] / st["rays"]
+        ctx.close()
+        out.append((res, visits))
+    assert (out[0][0][0] >= 0).mean() > 0.05
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
+    assert out[1][1] < 0.75 * out[0][1]  # four-child fetches per ray against two-child fetches
+
+
+def test_four_child_form_is_refused_for_other_widths_and_skipped_for_flat_scenes():
+    ctx = rtamd.Context(0)
+    with pytest.raises(rtamd.RtError):
+        ctx.set_bvh_width(3)
+    ctx.set_bvh_width(4)
+    assert ctx.load_scene("cornell_box", seed=1)["bvh_width"] == 2  # traced without a tree
+    ctx.close()
+
+
 # ---- degenerate inputs ------------------------------------------------------------------------------------
 def _raw_scene(ctx, builder, c0r, rects=None, moving=None):
     import ctypes as C
