@@ -106,12 +106,13 @@ L2_PER_XCD = 4 << 20  # a scene below this stays resident in every XCD's L2 for 
 
 def scene_bytes_per_ray(info, nodes_per_ray, prims_per_ray):
     """Algorithmic HBM bytes a ray needs from the scene description: 64 B per inner node fetched (two child boxes
-    + two references) and 32 B per primitive record tested -- unless the whole scene fits the 4 MiB L2 of an XCD.
+    + two references; 128 B where the tree is walked four children at a time, nodes_per_ray then counts those
+    fetches) and 32 B per primitive record tested -- unless the whole scene fits the 4 MiB L2 of an XCD.
     Then the launch reads it from HBM once per XCD and every further visit is a cache hit by construction
     (that part is added per launch, see scene_bytes_per_launch), so nothing is charged per ray."""
     if info["device_bytes"] <= L2_PER_XCD:
         return 0.0
-    return 64.0 * nodes_per_ray + 32.0 * prims_per_ray
+    return (128.0 if info.get("bvh_width", 2) == 4 else 64.0) * nodes_per_ray + 32.0 * prims_per_ray
 
 
 def scene_bytes_per_launch(info):
@@ -391,7 +392,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "frames": list(frames_cfg), "width": width, "height": frames[0].h,
                        "spp": spp, "max_depth": MAX_DEPTH, "tile_split": f"32x32 tiles round-robin over {world} rank(s)",
-                       "frames_at_once": bool(at_once),
+                       "frames_at_once": bool(at_once), "bvh_width": [f.info.get("bvh_width", 2) for f in frames],
                        "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps,
                        "sec_per_frame": round(elapsed / args.steps / len(frames), 5)},
             "roofline": roof,

@@ -75,7 +75,7 @@ pub struct rt_scene_info {
     pub build_seconds: f64,
     pub tree_seconds: f64,
     pub builder: u32,
-    pub reserved: u32,
+    pub bvh_width: u32,
 }
 #[repr(C)]
 #[derive(Default, Clone, Copy)]
@@ -143,6 +143,7 @@ extern "C" {
     pub fn rt_ctx_set_pipeline(ctx: *mut rt_ctx, pipeline: c_int) -> c_int;
     pub fn rt_ctx_set_tail_paths(ctx: *mut rt_ctx, tail_paths: u64) -> c_int;
     pub fn rt_ctx_set_builder(ctx: *mut rt_ctx, builder: c_int) -> c_int;
+    pub fn rt_ctx_set_bvh_width(ctx: *mut rt_ctx, width: c_int) -> c_int;
     pub fn rt_scene_clear(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_scene_set_spheres(ctx: *mut rt_ctx, n: u32, c0_r: *const f32, c1: *const f32, t01: *const f32,
                                 moving: *const u8, mat: *const u32, id: *const u32, group: *const u32) -> c_int;

@@ -134,11 +134,12 @@ int rt_scene_commit(rt_ctx* ctx, float shutter_t0, float shutter_t1);
  * primitives on, env RTAMD_GPU_BUILD_MIN), 0 = host, 1 = device (env RTAMD_BUILDER).  Every valid tree gives
  * the same hits; the builders differ in build time and in node visits per ray. */
 int rt_ctx_set_builder(rt_ctx* ctx, int builder);
-/* Children per inner node the kernels walk from the next rt_scene_commit on: 2 (default; 64-byte nodes holding both
- * child boxes) or 4 (env RTAMD_BVH_WIDTH=4: the finished tree, whichever builder made it, is also written in a
- * 128-byte four-child form -- the grandchildren of every node -- which halves the chain of dependent node fetches
- * per ray).  The reference's tree is binary (bvh_node.rs:26-30); the width changes no hit.  A tree whose four-child
- * walk could need more than 64 stack entries keeps the binary walk (rt_scene_info.bvh_width tells). */
+/* Children per inner node the kernels walk from the next rt_scene_commit on: 2 (64-byte nodes holding both child
+ * boxes), 4 (the finished tree, whichever builder made it, is also written in a 128-byte four-child form -- the
+ * grandchildren of every node -- which halves the chain of dependent node fetches per ray) or -1 = by tree size
+ * (default: 4 from 65536 nodes on, i.e. once the nodes outgrow one XCD's L2; env RTAMD_BVH_WIDTH, RTAMD_WIDE_MIN_NODES).
+ * The reference's tree is binary (bvh_node.rs:26-30); the width changes no hit.  A tree whose four-child walk could
+ * need more than 64 stack entries keeps the binary walk (rt_scene_info.bvh_width tells which one is in use). */
 int rt_ctx_set_bvh_width(rt_ctx* ctx, int width);
 
 typedef struct rt_scene_info {

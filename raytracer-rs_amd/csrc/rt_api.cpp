@@ -87,7 +87,8 @@ struct rt_ctx {
     uint64_t fused_node_limit = 64;  // scenes with more BVH nodes than this take deep_pipeline
     int builder = -1;  // world-level BVH: -1 by size, 0 host (binned SAH), 1 device (linear BVH)
     uint64_t gpu_build_min = 1u << 18;  // builder -1: worlds with at least this many primitives are built on the device
-    int bvh_width = 2;  // children per inner node the kernels walk: 2, or 4 (four-child form made at commit)
+    int bvh_width = -1;  // children per inner node the kernels walk: 2, 4 (four-child form made at commit), -1 by tree size
+    uint64_t wide_min_nodes = 1u << 16;  // bvh_width -1: trees of at least this many nodes (4 MiB, one XCD's L2) are walked four-wide
     DevBuf d_wide;
     uint64_t tail_paths = 256u << 10;  // a batch with at most this many live paths is finished by one k_finish launch
     rtk::SpillArea trace_spill;  // deep traversal-stack entries of k_trace (launch_trace grows it)
@@ -359,7 +360,11 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (getenv("RTAMD_TAIL_PATHS")) c->tail_paths = env_u32("RTAMD_TAIL_PATHS", 0);
     if (getenv("RTAMD_BUILDER")) c->builder = (int)std::min(env_u32("RTAMD_BUILDER", 0), 1u);
     if (getenv("RTAMD_GPU_BUILD_MIN")) c->gpu_build_min = env_u32("RTAMD_GPU_BUILD_MIN", 0);
-    if (getenv("RTAMD_BVH_WIDTH")) c->bvh_width = env_u32("RTAMD_BVH_WIDTH", 2) == 4 ? 4 : 2;
+    if (getenv("RTAMD_BVH_WIDTH")) {
+        const uint32_t w = env_u32("RTAMD_BVH_WIDTH", 0);
+        c->bvh_width = w == 4 ? 4 : (w == 2 ? 2 : -1);
+    }
+    if (getenv("RTAMD_WIDE_MIN_NODES")) c->wide_min_nodes = env_u32("RTAMD_WIDE_MIN_NODES", 0);
     *out = c;
     return RT_OK;
 }
@@ -406,7 +411,7 @@ int rt_ctx_set_builder(rt_ctx* c, int builder) {
     return RT_OK;
 }
 int rt_ctx_set_bvh_width(rt_ctx* c, int width) {
-    if (!c || (width != 2 && width != 4)) return fail(c, RT_ERR_INVALID, "bvh width must be 2 or 4");
+    if (!c || (width != 2 && width != 4 && width != -1)) return fail(c, RT_ERR_INVALID, "bvh width must be -1, 2 or 4");
     c->bvh_width = width;
     return RT_OK;
 }
@@ -796,7 +801,8 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     // Four-child walk: a node covers two binary levels and leaves up to three entries behind.  The top level, the
     // device-built world tree and the instances' trees are widened separately (each from its own root).
     const uint32_t need_wide = 3u * ((top_r.depth + 1) / 2 + (lbvh_depth + 1) / 2 + (n_inst ? (blas_depth + 1) / 2 : 0)) + (n_inst ? 1 : 0) + 1;
-    const bool wide = c->bvh_width == 4 && !flat_ok && n_nodes_total > 0 && need_wide <= 64;
+    const bool want_wide = c->bvh_width == 4 || (c->bvh_width < 0 && n_nodes_total >= c->wide_min_nodes);
+    const bool wide = want_wide && !flat_ok && n_nodes_total > 0 && need_wide <= 64;
     if (wide) {
         need = need_wide;
         if ((rc = ensure(c, c->d_wide, n_nodes_total * sizeof(rtd::WideNode)))) return rc;

@@ -319,7 +319,7 @@ class Context:
         self._check(self.L.rt_ctx_set_pipeline(self.h, pipeline))
 
     def set_bvh_width(self, width):
-        """Children per inner node the kernels walk from the next commit on: 2 or 4 (same hits either way)."""
+        """Children per inner node the kernels walk from the next commit on: 2, 4, or -1 = by tree size (same hits either way)."""
         self._check(self.L.rt_ctx_set_bvh_width(self.h, width))
 
     def set_builder(self, builder):

@@ -156,6 +156,9 @@ def test_four_child_form_is_refused_for_other_widths_and_skipped_for_flat_scenes
         ctx.set_bvh_width(3)
     ctx.set_bvh_width(4)
     assert ctx.load_scene("cornell_box", seed=1)["bvh_width"] == 2  # traced without a tree
+    ctx.set_bvh_width(-1)  # by size: four-wide once the nodes outgrow one XCD's L2
+    assert ctx.load_scene("random_world", seed=1)["bvh_width"] == 2
+    assert ctx.load_scene("synth_spheres", seed=1, n_synth=70_000)["bvh_width"] == 4
     ctx.close()
 
 
