@@ -49,7 +49,9 @@ int rt_ctx_synchronize(rt_ctx* ctx);
 /* Kernel pipeline of rt_render: -1 = pick per scene (default), 0 = split (ray generation, then a trace and
  * a shade kernel per bounce), 1 = fused (one kernel per bounce), 2 = hybrid (bounce 0 fused, later bounces
  * split), 3 = whole paths (one launch per batch: every lane follows a path to its end and then starts the next
- * one; no path queues).  All produce the same bits. */
+ * one; no path queues).  All produce the same bits.  -1 takes 3 for small scenes traced without a tree and with
+ * cheap shading, 1 for other scenes of up to 64 nodes, 0 for trees whose nodes outgrow the 256 MB Infinity Cache
+ * and 2 for everything in between. */
 int rt_ctx_set_pipeline(rt_ctx* ctx, int pipeline);
 /* Once a batch has at most tail_paths live paths, one kernel launch walks each of them to its end
  * instead of one launch per bounce (default 262144, env RTAMD_TAIL_PATHS; 0 = never).  The image does not depend on it. */

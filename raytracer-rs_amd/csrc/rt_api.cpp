@@ -85,6 +85,7 @@ struct rt_ctx {
     uint32_t n_perlin_tables = 0;  // of the committed scene
     bool whole_paths_auto = true;  // pipeline -1 may pick 3 (whole paths) for flat scenes; env RTAMD_WHOLE_PATHS=0 turns that off
     uint64_t fused_node_limit = 64;  // scenes with more BVH nodes than this take deep_pipeline
+    uint64_t split_min_node_bytes = 256ull << 20;  // trees whose nodes outgrow the 256 MB Infinity Cache take the split pipeline
     int builder = -1;  // world-level BVH: -1 by size, 0 host (binned SAH), 1 device (linear BVH)
     uint64_t gpu_build_min = 1u << 18;  // builder -1: worlds with at least this many primitives are built on the device
     int bvh_width = -1;  // children per inner node the kernels walk: 2, 4 (four-child form made at commit), -1 by tree size
@@ -356,6 +357,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (getenv("RTAMD_PIPELINE")) c->pipeline = (int)std::min(env_u32("RTAMD_PIPELINE", 1), 3u);  // 0 split, 1 fused, 2 hybrid, 3 whole paths
     if (getenv("RTAMD_DEEP_PIPELINE")) c->deep_pipeline = (int)std::min(env_u32("RTAMD_DEEP_PIPELINE", 2), 2u);
     if (getenv("RTAMD_FUSED_NODE_LIMIT")) c->fused_node_limit = env_u32("RTAMD_FUSED_NODE_LIMIT", 0);
+    if (getenv("RTAMD_SPLIT_MIN_NODE_MB")) c->split_min_node_bytes = (uint64_t)env_u32("RTAMD_SPLIT_MIN_NODE_MB", 256) << 20;
     if (getenv("RTAMD_WHOLE_PATHS")) c->whole_paths_auto = env_u32("RTAMD_WHOLE_PATHS", 1) != 0;
     if (getenv("RTAMD_TAIL_PATHS")) c->tail_paths = env_u32("RTAMD_TAIL_PATHS", 0);
     if (getenv("RTAMD_BUILDER")) c->builder = (int)std::min(env_u32("RTAMD_BUILDER", 0), 1u);
@@ -1101,8 +1103,14 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     // already VALU-bound (two_perlin_spheres 39 vs 43 ms), and long paths drain slowly at the end of a wave's run
     // (cornell_smoke 130 vs 165 ms; cornell_box, closed as well, is level at best).  Instances stand for those here.
     const bool whole_paths = c->scene.flat && c->n_perlin_tables == 0 && !c->has_groups && c->whole_paths_auto;
+    // Once the nodes the kernels walk no longer fit the Infinity Cache, the fused camera-ray launch (whole stack in
+    // LDS, one ray per lane from start to end) falls behind the persistent trace waves, which refill their lanes
+    // and keep only eight stack entries in LDS: 10 M spheres 78 vs 91 ms per 16-spp frame with the split pipeline,
+    // 1 M level, 0.3 M and smaller 8-25 % the other way.
+    const uint64_t walked_node_bytes = c->info.n_nodes * (c->info.bvh_width == 4 ? sizeof(rtd::WideNode) : sizeof(rtd::Node));
+    const int deep = walked_node_bytes >= c->split_min_node_bytes ? 0 : c->deep_pipeline;
     const int mode = c->pipeline >= 0 ? c->pipeline
-                                      : (whole_paths ? 3 : (c->info.n_nodes <= c->fused_node_limit ? 1 : c->deep_pipeline));
+                                      : (whole_paths ? 3 : (c->info.n_nodes <= c->fused_node_limit ? 1 : deep));
     // (flat scenes have no nodes to speak of and always fall on the fused side)
     const bool fused = mode == 1 || mode == 3;  // (the instrumented passes of mode 3 run the fused kernels)
     st.pipeline = (uint32_t)mode;
