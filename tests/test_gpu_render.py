@@ -300,6 +300,41 @@ def test_fused_and_split_pipelines_give_the_same_bits(name):
         assert np.array_equal(out[0][0], out[pipe][0])
 
 
+def test_exact_pixels_light_from_behind_background_and_depth_limit():
+    """Three facts of ray_color (main.rs:44-63) that fix pixels exactly, with no sampling noise: a DiffuseLight
+    emits from both faces (materials.rs:176-184), a miss returns the flat background (main.rs:60-62), and a path
+    that runs out of depth contributes nothing (main.rs:45-47)."""
+    texs = [rtamd.rt_texture(kind=0, color=(C.c_float * 3)(4.0, 2.0, 1.0)), rtamd.rt_texture(kind=0, color=(C.c_float * 3)(0.5, 0.5, 0.5))]
+    mats = [rtamd.rt_material(kind=3, tex=0), rtamd.rt_material(kind=0, tex=1)]
+    # an XY rect at z = 0 facing +z (shapes.rs:279-306), looked at from z = -10, i.e. from behind
+    rects = dict(axis=np.uint8([0]), k=np.float32([0.0]), bounds=np.float32([[-1, -1, 1, 1]]), mat=np.uint32([0]), id=np.uint32([0]))
+    cam = rtamd.camera_new((0, 0, -10), (0, 0, 0), (0, 1, 0), math.radians(40), 1.0, 0.0, 10.0, 0.0, 1.0)
+    bg = np.float32([0.25, 0.5, 0.75])
+    w = h = 64
+    spp = 4
+    ctx = rtamd.Context(0)
+    for pipe in (0, 1, 2, 3):
+        ctx.set_pipeline(pipe)
+        ctx.set_scene(rects=rects, materials=mats, textures=texs)
+        img, st = ctx.render(w, h, cam, spp, depth=50, seed=3, background=bg)
+        px = img.reshape(-1, 3)
+        lit = np.all(px == np.float32([4.0, 2.0, 1.0]) * spp, axis=1)
+        sky = np.all(px == bg * spp, axis=1)
+        edge = ~(lit | sky)  # pixels whose samples fall on both sides of the rect's outline
+        assert lit.sum() > 200 and sky.sum() > 2000 and edge.sum() < 4 * 80
+        assert st["rays"] == w * h * spp  # neither a light nor a miss scatters
+        # a grey Lambertian sphere with depth 1: the scattered ray is never followed, hit pixels are black
+        sph = dict(c0r=np.float32([[0, 0, 0, 1]]), mat=np.uint32([1]), id=np.uint32([0]))
+        ctx.set_scene(spheres=sph, materials=mats, textures=texs)
+        img, st = ctx.render(w, h, cam, spp, depth=1, seed=3, background=bg)
+        px = img.reshape(-1, 3)
+        black = np.all(px == 0.0, axis=1)
+        sky = np.all(px == bg * spp, axis=1)
+        assert black.sum() > 150 and sky.sum() > 2000 and (~(black | sky)).sum() < 4 * 80
+        assert st["rays"] == w * h * spp
+    ctx.close()
+
+
 def test_contexts_render_concurrently_from_host_threads():
     """Contexts are independent: three of them, each on its own HIP stream and driven by its own host thread, render
     different scenes at the same time and give the images and ray counts that they give one after the other."""
