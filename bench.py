@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--synth-n", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="CPU work the cpu_baseline sample is sized to")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing (roofline becomes null)")
     ap.add_argument("--frames-at-once", type=int, default=-1, choices=[-1, 0, 1],
                     help="render the frames of a step concurrently, one HIP stream and host thread each (default: only "
@@ -398,7 +399,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames_cfg, width, aspect)
+            out["cpu_baseline"] = cpu_baseline(frames_cfg, width, aspect, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

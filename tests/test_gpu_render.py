@@ -502,3 +502,32 @@ def test_cpp_example_renders_the_same_image_as_the_python_binding(tmp_path):
     ref = ctx.resolve_u8(img, 6)
     ctx.close()
     assert np.array_equal(np.asarray(Image.open(out)), ref)
+
+
+def test_bench_line_keeps_its_contract():
+    """bench.py prints ONE JSON line; the keys the harness reads, the roofline and the CPU baseline object are there,
+    and the rates follow from the counts in the same line (small frame, one step)."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(orc.ROOT / "bench.py"), "--width", "320", "--spp", "4", "--steps", "1", "--warmup", "1",
+                        "--cpu-baseline-seconds", "3"],
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    cfg = d["config"]
+    assert cfg["workload"] == "c2_textures" and cfg["width"] == 320 and cfg["spp"] == 4
+    assert cfg["paths_per_step"] == 3 * 320 * 180 * 4 and cfg["rays_per_step"] > cfg["paths_per_step"]
+    assert d["value"] == pytest.approx(cfg["rays_per_step"] / d["ms_per_step"] / 1e3, rel=1e-3)
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-3) and roof["avg_launch_ms"] > 0
+    assert roof["achieved"] == pytest.approx(roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-3)
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "Mrays/s" and cpu["sample"]
