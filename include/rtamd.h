@@ -164,6 +164,9 @@ int rt_scene_read_bvh(rt_ctx* ctx, void* nodes, uint64_t nodes_bytes, void* prim
                       uint32_t* root_ref);
 
 /* ---- camera (camera.rs:14-25; built by Camera::new, camera.rs:28-52) ------ */
+/* time_start..time_end is the interval Camera::get_ray draws ray times from (camera.rs:63).  When the scene has
+ * moving spheres it must lie inside the shutter interval given to rt_scene_commit, whose boxes cover only that
+ * interval (rt_render returns RT_ERR_INVALID otherwise). */
 typedef struct rt_camera {
     float origin[3];
     float lower_left_corner[3];
@@ -252,6 +255,15 @@ int rt_accum_write(const char* path, uint32_t width, uint32_t height, uint32_t s
                    const float* accum_rgb);
 int rt_accum_read(const char* path, uint32_t* width, uint32_t* height, uint32_t* samples_done, uint32_t* seed,
                   float* accum_rgb, uint64_t cap_floats);
+/* The same with a caller-supplied 64-bit tag (a hash of whatever must not change between the two halves of a
+ * render: scene, camera, max_depth, background) stored in the file and returned for comparison, since the sums
+ * only continue bit-exactly under the same scene and camera.  rt_accum_write stores tag 0.  The file is written
+ * to "<path>.tmp", flushed to the disk and renamed over the target, so an interruption never destroys the
+ * previous checkpoint. */
+int rt_accum_write_tagged(const char* path, uint32_t width, uint32_t height, uint32_t samples_done, uint32_t seed,
+                          uint64_t tag, const float* accum_rgb);
+int rt_accum_read_tagged(const char* path, uint32_t* width, uint32_t* height, uint32_t* samples_done, uint32_t* seed,
+                         uint64_t* tag, float* accum_rgb, uint64_t cap_floats);
 
 /* Pixels owned by `rank` under the tile deal of rt_render, in render order (tile-major). Writes up to
  * cap pixel indices (y*width+x) to out (host) and returns the count in *n. */

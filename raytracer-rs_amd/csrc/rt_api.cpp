@@ -69,6 +69,8 @@ struct rt_ctx {
 
     // device scene
     bool committed = false;
+    float shutter_t0 = 0.0f, shutter_t1 = 1.0f;  // of the last commit: the interval the moving spheres' boxes cover
+    bool has_moving = false;
     DevBuf d_prims, d_moving, d_nodes, d_groups, d_mats, d_texs, d_perlin, d_images, d_media;
     std::vector<DevBuf> d_image_data;
     rtd::Scene scene{};
@@ -893,7 +895,9 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.root_ref = top_r.root_ref;
     S.n_prims = (uint32_t)n_prims_total;
     S.n_groups = ng;
-    S.n_media = n_media;
+    // media[] holds only the media that have a boundary: a ConstantMedium around nothing can never be hit, so it
+    // is not evaluated (its Group::order still counts it, which keeps the other media's RNG salts where they were)
+    S.n_media = (uint32_t)media_groups.size();
     S.flat = flat_ok ? 1u : 0u;
     S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
     c->n_perlin_tables = n_perlin;
@@ -918,6 +922,9 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
                            c->mats.size() * sizeof(rt_material) + c->texs.size() * sizeof(rt_texture) +
                            ptab.size() * sizeof(rtd::PerlinTable) + image_bytes;
     c->info.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
+    c->shutter_t0 = shutter_t0;
+    c->shutter_t1 = shutter_t1;
+    c->has_moving = !moving.empty();
     c->committed = true;
     return RT_OK;
 }
@@ -1050,6 +1057,11 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (!(cam->time_start < cam->time_end) || !std::isfinite(cam->time_end - cam->time_start))
         return fail(c, RT_ERR_INVALID, "rt_render: camera needs finite time_start < time_end");
     if (!std::isfinite(cam->lens_radius)) return fail(c, RT_ERR_INVALID, "rt_render: camera lens_radius is not finite");
+    // The boxes of moving spheres cover the shutter interval given to rt_scene_commit (MovingSphere::bounding_box,
+    // shapes.rs:236-249, over the t0..t1 of BVHNode::from_scene): a ray time outside it would be culled by the tree
+    // and still hit in a flat scene.  gen_range(time_start..time_end) draws from [time_start, time_end).
+    if (c->has_moving && !(cam->time_start >= std::min(c->shutter_t0, c->shutter_t1) && cam->time_end <= std::max(c->shutter_t0, c->shutter_t1)))
+        return fail(c, RT_ERR_INVALID, "rt_render: camera time range lies outside the shutter interval of rt_scene_commit (the scene has moving spheres)");
     const uint32_t ts = p->tile_size ? p->tile_size : 32, nranks = p->nranks ? p->nranks : 1;
     if (p->rank >= nranks) return fail(c, RT_ERR_INVALID, "rt_render: rank >= nranks");
     HIP_TRY(c, hipSetDevice(c->device));

@@ -7,10 +7,12 @@
 //                    be continued with rt_render(sample0 = samples_done, ...) and still match an uninterrupted
 //                    one bit for bit (the sums are added in sample order either way).
 // No GPU is involved; these calls work without a device.
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/rtamd.h"
@@ -30,17 +32,29 @@ void put_chunk(std::vector<uint8_t>& png, const char type[4], const uint8_t* dat
     if (n) png.insert(png.end(), data, data + n);
     put_be32(png, (uint32_t)crc32(0L, png.data() + at, (uInt)(n + 4)));
 }
+// Writes to "<path>.tmp", flushes it to the disk and renames it over the target: an interruption leaves either the
+// old file or the new one, never a torn one (a checkpoint is the only resume point of a long render).
 bool write_all(const char* path, const void* a, size_t na, const void* b, size_t nb) {
-    FILE* f = fopen(path, "wb");
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return false;
     bool ok = (na == 0 || fwrite(a, 1, na, f) == na) && (nb == 0 || fwrite(b, 1, nb, f) == nb);
+    ok = (fflush(f) == 0) && ok;
+    ok = (fsync(fileno(f)) == 0) && ok;
     ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path) == 0;
+    if (!ok) (void)remove(tmp.c_str());
     return ok;
 }
 
+// Version 1 files end after `seed`; version 2 adds the caller's tag.
 struct AccumHeader {
-    char magic[8];  // "RTACCUM1"
+    char magic[8];  // "RTACCUM1" / "RTACCUM2"
     uint32_t width, height, samples_done, seed;
+};
+struct AccumHeader2 {
+    AccumHeader h;
+    uint64_t tag;
 };
 
 }  // namespace
@@ -77,27 +91,40 @@ int rt_image_write(const char* path, uint32_t width, uint32_t height, const uint
     return write_all(path, png.data(), png.size(), nullptr, 0) ? RT_OK : RT_ERR_IO;
 }
 
-int rt_accum_write(const char* path, uint32_t width, uint32_t height, uint32_t samples_done, uint32_t seed, const float* accum_rgb) {
+int rt_accum_write_tagged(const char* path, uint32_t width, uint32_t height, uint32_t samples_done, uint32_t seed, uint64_t tag,
+                          const float* accum_rgb) {
     if (!path || !accum_rgb || !width || !height) return RT_ERR_INVALID;
-    AccumHeader h;
-    memcpy(h.magic, "RTACCUM1", 8);
-    h.width = width;
-    h.height = height;
-    h.samples_done = samples_done;
-    h.seed = seed;
+    AccumHeader2 h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.h.magic, "RTACCUM2", 8);
+    h.h.width = width;
+    h.h.height = height;
+    h.h.samples_done = samples_done;
+    h.h.seed = seed;
+    h.tag = tag;
     return write_all(path, &h, sizeof(h), accum_rgb, (size_t)width * height * 3 * sizeof(float)) ? RT_OK : RT_ERR_IO;
 }
+int rt_accum_write(const char* path, uint32_t width, uint32_t height, uint32_t samples_done, uint32_t seed, const float* accum_rgb) {
+    return rt_accum_write_tagged(path, width, height, samples_done, seed, 0, accum_rgb);
+}
 
-int rt_accum_read(const char* path, uint32_t* width, uint32_t* height, uint32_t* samples_done, uint32_t* seed, float* accum_rgb,
-                  uint64_t cap_floats) {
+int rt_accum_read_tagged(const char* path, uint32_t* width, uint32_t* height, uint32_t* samples_done, uint32_t* seed, uint64_t* tag,
+                         float* accum_rgb, uint64_t cap_floats) {
     if (!path) return RT_ERR_INVALID;
     FILE* f = fopen(path, "rb");
     if (!f) return RT_ERR_IO;
     AccumHeader h;
+    uint64_t file_tag = 0;
     int rc = RT_OK;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RTACCUM1", 8) != 0 || !h.width || !h.height) {
+    bool head_ok = fread(&h, sizeof(h), 1, f) == 1 && h.width && h.height;
+    if (head_ok && memcmp(h.magic, "RTACCUM2", 8) == 0)
+        head_ok = fread(&file_tag, sizeof(file_tag), 1, f) == 1;
+    else if (head_ok)
+        head_ok = memcmp(h.magic, "RTACCUM1", 8) == 0;  // files written before the tag existed: tag 0
+    if (!head_ok) {
         rc = RT_ERR_IO;
     } else {
+        if (tag) *tag = file_tag;
         if (width) *width = h.width;
         if (height) *height = h.height;
         if (samples_done) *samples_done = h.samples_done;
@@ -112,6 +139,10 @@ int rt_accum_read(const char* path, uint32_t* width, uint32_t* height, uint32_t*
     }
     fclose(f);
     return rc;
+}
+int rt_accum_read(const char* path, uint32_t* width, uint32_t* height, uint32_t* samples_done, uint32_t* seed, float* accum_rgb,
+                  uint64_t cap_floats) {
+    return rt_accum_read_tagged(path, width, height, samples_done, seed, nullptr, accum_rgb, cap_floats);
 }
 
 }  // extern "C"

@@ -32,7 +32,8 @@ ABI_SYMBOLS = (
     "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_reserve", "rt_ctx_set_builder", "rt_ctx_set_bvh_width", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
-    "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_accum_write", "rt_accum_read", "rt_owned_pixels")
+    "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_accum_write", "rt_accum_read", "rt_accum_write_tagged",
+    "rt_accum_read_tagged", "rt_owned_pixels")
 
 
 class RtError(RuntimeError):
@@ -144,6 +145,8 @@ def core():
     L.rt_image_write.argtypes = [C.c_char_p, u32, u32, vp, C.c_int]
     L.rt_accum_write.argtypes = [C.c_char_p, u32, u32, u32, u32, vp]
     L.rt_accum_read.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, u64]
+    L.rt_accum_write_tagged.argtypes = [C.c_char_p, u32, u32, u32, u32, u64, vp]
+    L.rt_accum_read_tagged.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), vp, u64]
     L.rt_owned_pixels.argtypes = [u32, u32, u32, u32, u32, vp, u64, C.POINTER(u64)]
     for s in ABI_SYMBOLS:
         fn = getattr(L, s)
@@ -195,10 +198,33 @@ def _ptr(a):
     if a is None:
         return None
     if _is_torch(a):
-        assert a.is_contiguous()
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
         return C.c_void_p(a.data_ptr())
-    assert a.flags["C_CONTIGUOUS"]
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _check_array(a, what, dtype_name, shape, device=None):
+    """The C ABI takes raw pointers: a buffer of another dtype, shape, layout or GPU would be written out of
+    bounds, so it is refused here.  shape entries of None match anything."""
+    if _is_torch(a):
+        ok_dtype = str(a.dtype) == "torch." + dtype_name
+        contiguous = a.is_contiguous()
+        if a.is_cuda and device is not None and a.device.index != device:
+            raise ValueError(f"{what}: tensor lives on cuda:{a.device.index}, the context on cuda:{device}")
+    else:
+        if not isinstance(a, np.ndarray):
+            raise ValueError(f"{what}: numpy array or torch tensor expected, got {type(a).__name__}")
+        ok_dtype = a.dtype == np.dtype(dtype_name)
+        contiguous = a.flags["C_CONTIGUOUS"]
+    if not ok_dtype:
+        raise ValueError(f"{what}: dtype must be {dtype_name}, got {a.dtype}")
+    if len(a.shape) != len(shape) or any(s is not None and int(d) != s for d, s in zip(a.shape, shape)):
+        raise ValueError(f"{what}: shape must be {tuple('*' if s is None else s for s in shape)}, got {tuple(a.shape)}")
+    if not contiguous:
+        raise ValueError(f"{what}: must be C-contiguous")
 
 
 def camera_new(origin, target, up, vfov_rad, aspect, aperture, focus, t0, t1):
@@ -251,27 +277,28 @@ def write_image(path, rgb8, fmt="png"):
         raise RtError(rc, f"rt_image_write({path})")
 
 
-def save_accum(path, accum, samples_done, seed):
-    """Checkpoint of a progressive render: f32 sample sums (h, w, 3) + how many samples they hold + the seed."""
+def save_accum(path, accum, samples_done, seed, tag=0):
+    """Checkpoint of a progressive render: f32 sample sums (h, w, 3) + how many samples they hold + the seed + a
+    caller's 64-bit tag (hash of scene, camera, depth ...).  Written to a temporary file and renamed."""
     a = np.ascontiguousarray(accum.cpu().numpy() if _is_torch(accum) else accum, dtype=np.float32)
     h, w, _ = a.shape
-    rc = core().rt_accum_write(str(path).encode(), w, h, samples_done, seed, a.ctypes.data)
+    rc = core().rt_accum_write_tagged(str(path).encode(), w, h, samples_done, seed, int(tag), a.ctypes.data)
     if rc:
-        raise RtError(rc, f"rt_accum_write({path})")
+        raise RtError(rc, f"rt_accum_write_tagged({path})")
 
 
-def load_accum(path):
-    """-> (accum (h, w, 3) float32, samples_done, seed); continue with render(..., sample0=samples_done, accum=accum)."""
+def load_accum(path, with_tag=False):
+    """-> (accum (h, w, 3) float32, samples_done, seed[, tag]); continue with render(..., sample0=samples_done, accum=accum)."""
     L = core()
-    w, h, done, seed = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-    rc = L.rt_accum_read(str(path).encode(), C.byref(w), C.byref(h), C.byref(done), C.byref(seed), None, 0)
+    w, h, done, seed, tag = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+    rc = L.rt_accum_read_tagged(str(path).encode(), C.byref(w), C.byref(h), C.byref(done), C.byref(seed), C.byref(tag), None, 0)
     if rc:
-        raise RtError(rc, f"rt_accum_read({path})")
+        raise RtError(rc, f"rt_accum_read_tagged({path})")
     a = np.empty((h.value, w.value, 3), np.float32)
-    rc = L.rt_accum_read(str(path).encode(), None, None, None, None, a.ctypes.data, a.size)
+    rc = L.rt_accum_read_tagged(str(path).encode(), None, None, None, None, None, a.ctypes.data, a.size)
     if rc:
-        raise RtError(rc, f"rt_accum_read({path})")
-    return a, done.value, seed.value
+        raise RtError(rc, f"rt_accum_read_tagged({path})")
+    return (a, done.value, seed.value, tag.value) if with_tag else (a, done.value, seed.value)
 
 
 class Context:
@@ -284,6 +311,7 @@ class Context:
         if rc != RT_OK:
             raise RtError(rc, "rt_ctx_create failed (no GPU visible?)")
         self.h = h
+        self.device = device
         self.scene_handle = None
         self.scene_name = None
         if max_paths:
@@ -447,13 +475,15 @@ class Context:
     # ---- work ----------------------------------------------------------------------
     def intersect(self, rays, tmin=0.005, tmax=float("inf"), seed=1, outputs=None):
         """rays: (7, n) float32 numpy array or torch CUDA tensor.  Returns a dict of arrays of the same kind."""
+        if not _is_torch(rays):
+            rays = np.ascontiguousarray(rays, dtype=np.float32)
+        _check_array(rays, "rays", "float32", (7, None), self.device)
         n = rays.shape[1]
         if _is_torch(rays):
             import torch
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=rays.device)
             i32, f32, u8 = torch.int32, torch.float32, torch.uint8
         else:
-            rays = np.ascontiguousarray(rays, dtype=np.float32)
             mk = lambda shape, dt: np.empty(shape, dtype=dt)
             i32, f32, u8 = np.int32, np.float32, np.uint8
         out = dict(prim=mk((n,), i32), inst=mk((n,), i32), t=mk((n,), f32), normal=mk((n, 3), f32), front=mk((n,), u8),
@@ -471,6 +501,7 @@ class Context:
         (accum, stats dict)."""
         if accum is None:
             accum = np.zeros((height, width, 3), dtype=np.float32)
+        _check_array(accum, "accum", "float32", (height, width, 3), self.device)
         p = rt_render_params()
         p.width, p.height = width, height
         p.sample0, p.sample1 = sample0, sample0 + spp
@@ -485,6 +516,7 @@ class Context:
 
     def resolve_u8(self, accum, spp, transfer=0):
         """transfer 0: linear (main.rs:307-313); 1: square root first (the commented-out write_color, main.rs:35-42)."""
+        _check_array(accum, "accum", "float32", (None, None, 3), self.device)
         if _is_torch(accum):
             import torch
             out = torch.empty(accum.shape, dtype=torch.uint8, device=accum.device)

@@ -256,3 +256,33 @@ def test_accum_checkpoint_round_trip(tmp_path):
         rtamd.load_accum(tmp_path / "bad.acc")
     with pytest.raises(rtamd.RtError):
         rtamd.load_accum(tmp_path / "missing.acc")
+    # the tag travels with the file; an overwrite goes through "<path>.tmp" + rename and leaves no temporary behind
+    rtamd.save_accum(tmp_path / "c.acc", acc * 2, 38, 12345, tag=0xDEADBEEFCAFEF00D)
+    back, done, seed, tag = rtamd.load_accum(tmp_path / "c.acc", with_tag=True)
+    assert done == 38 and tag == 0xDEADBEEFCAFEF00D and np.array_equal(back, acc * 2)
+    assert sorted(q.name for q in tmp_path.iterdir()) == ["bad.acc", "c.acc"]
+    # a file of the first format (no tag field) still loads, with tag 0
+    import struct
+    (tmp_path / "v1.acc").write_bytes(b"RTACCUM1" + struct.pack("<4I", 17, 9, 5, 77) + acc.tobytes())
+    back, done, seed, tag = rtamd.load_accum(tmp_path / "v1.acc", with_tag=True)
+    assert (done, seed, tag) == (5, 77, 0) and np.array_equal(back, acc)
+    # a write that cannot be completed leaves the previous checkpoint alone
+    with pytest.raises(rtamd.RtError):
+        rtamd.save_accum(tmp_path / "no_such_dir" / "c.acc", acc, 1, 1)
+
+
+def test_binding_refuses_buffers_of_the_wrong_kind():
+    """The C ABI takes raw pointers, so the binding checks dtype, shape and layout before it passes one on."""
+    for bad in (np.zeros((4, 4, 3), np.float64), np.zeros((4, 4, 4), np.float32), np.zeros((4, 8, 3), np.float32)[:, ::2], [1.0]):
+        with pytest.raises(ValueError):
+            rtamd._check_array(bad, "accum", "float32", (4, 4, 3))
+    rtamd._check_array(np.zeros((4, 4, 3), np.float32), "accum", "float32", (4, 4, 3))
+    rtamd._check_array(np.zeros((7, 5), np.float32), "rays", "float32", (7, None))
+    with pytest.raises(ValueError):
+        rtamd._check_array(np.zeros((6, 5), np.float32), "rays", "float32", (7, None))
+    import torch
+    with pytest.raises(ValueError):
+        rtamd._check_array(torch.zeros((4, 4, 3), dtype=torch.float64), "accum", "float32", (4, 4, 3))
+    with pytest.raises(ValueError):
+        rtamd._check_array(torch.zeros((4, 3, 4)).permute(0, 2, 1), "accum", "float32", (4, 4, 3))
+    rtamd._check_array(torch.zeros((4, 4, 3)), "accum", "float32", (4, 4, 3))

@@ -125,6 +125,41 @@ def test_kat_instance_and_medium(gpu_ctx):
     assert (r["prim"] == -2).sum() > 40
 
 
+def test_empty_medium_group_is_never_hit(gpu_ctx):
+    """A ConstantMedium whose boundary holds no primitive (group 1) next to a normal one (group 2): the empty one
+    must not be evaluated -- it has no record in the device's media list -- and the other keeps medium index 1,
+    i.e. its RNG salt and the id it reports."""
+    mats, texs = solid_lambertian()
+    mats.append(rtamd.rt_material(kind=4, tex=0))
+    density = 0.5
+    empty = rtamd.rt_group(kind=2, has_xform=0, neg_inv_density=-1.0 / density, mat=1)
+    full = rtamd.rt_group(kind=2, has_xform=0, neg_inv_density=-1.0 / density, mat=1)
+    info = gpu_ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 2]], mat=[0], id=[0], group=[2]), groups=[empty, full], materials=mats, textures=texs)
+    assert info["n_media"] == 2
+    rays = np.repeat(one_ray((0, 0, -5), (0, 0, 1)), 256, axis=1)
+    r = gpu_ctx.intersect(rays, seed=11)
+    n_hit = 0
+    for i in range(256):
+        xi = orc.lib().orc_rng_medium_xi(11, i, 0, 0, 1)
+        hit = -math.log(xi) / density
+        if hit > 4.0:
+            assert r["prim"][i] == -1
+        else:
+            n_hit += 1
+            assert r["prim"][i] == -3 and r["t"][i] == pytest.approx(3.0 + hit, rel=1e-6)
+    assert n_hit > 150
+    cam = rtamd.camera_new((0, 0, -5), (0, 0, 0), (0, 1, 0), 0.5, 1.0, 0.0, 10.0, 0.0, 1.0)
+    for pipe in (0, 1):  # rt_render walks the same media list (k_shade and the fused kernel)
+        gpu_ctx.set_pipeline(pipe)
+        img, st = gpu_ctx.render(16, 16, cam, 4, background=(1.0, 1.0, 1.0))
+        assert np.isfinite(img).all() and st["rays"] > 16 * 16 * 4
+    gpu_ctx.set_pipeline(-1)
+    # only empty media: nothing to hit at all
+    gpu_ctx.set_scene(spheres=dict(c0r=[[0, 0, 9, 1]], mat=[0], id=[0]), groups=[empty], materials=mats, textures=texs)
+    r = gpu_ctx.intersect(one_ray((0, 0, -5), (0, 0, 1)))
+    assert r["prim"][0] == 0 and r["t"][0] == 13.0
+
+
 def test_error_paths(gpu_ctx):
     ctx = rtamd.Context(0)
     with pytest.raises(rtamd.RtError) as e:
@@ -151,6 +186,22 @@ def test_error_paths(gpu_ctx):
     with pytest.raises(rtamd.RtError) as e:
         ctx.render(8, 8, still, 1)
     assert "time" in str(e.value)
+    with pytest.raises(ValueError):
+        ctx.render(8, 8, cam, 1, accum=np.zeros((8, 8, 3), np.float64))
+    with pytest.raises(ValueError):
+        ctx.render(8, 8, cam, 1, accum=np.zeros((8, 8, 4), np.float32))
+    # a static scene takes any ray-time interval; with a moving sphere the interval must lie inside the shutter
+    # interval of the commit, whose boxes cover nothing else (shapes.rs:236-249)
+    late = rtamd.camera_new((0, 0, -5), (0, 0, 0), (0, 1, 0), 0.5, 1.0, 0.0, 10.0, 1.0, 2.0)
+    ctx.render(8, 8, late, 1)
+    moving = dict(c0r=[[0, 0, 0, 1]], c1=[[1, 0, 0]], t01=[[0, 1]], moving=[1], mat=[0], id=[0])
+    ctx.set_scene(spheres=moving, materials=mats, textures=texs, shutter=(0.0, 1.0))
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.render(8, 8, late, 1)
+    assert e.value.code == -1 and "shutter" in str(e.value)
+    ctx.set_scene(spheres=moving, materials=mats, textures=texs, shutter=(0.0, 2.0))
+    ctx.render(8, 8, late, 1)
+    ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0]), materials=mats, textures=texs)
     img, st = ctx.render(8, 8, cam, 2, depth=253)
     assert st["rays"] >= 128 and np.isfinite(img).all()
     ctx.reserve(1 << 20)  # queues allocated ahead of time: same image
