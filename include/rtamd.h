@@ -144,6 +144,14 @@ int rt_ctx_set_builder(rt_ctx* ctx, int builder);
  * need more than 64 stack entries keeps the binary walk (rt_scene_info.bvh_width tells which one is in use). */
 int rt_ctx_set_bvh_width(rt_ctx* ctx, int width);
 
+/* Six rects that are exactly what Box2::full_box emits (shapes.rs:456-466: consecutive ids, one material, side
+ * order XY(min.z), XY(max.z), XZ(min.y), XZ(max.y), YZ(min.x), YZ(max.x), bounds equal bit for bit to the corners)
+ * are kept as ONE record and one BVH leaf from the next rt_scene_commit on (default on; env RTAMD_FUSE_BOXES=0).
+ * The kernels still run the six rect tests in that order with the reference's arithmetic, so hits, reported ids
+ * and ties do not change; the tree gets two to three levels shallower where boxes dominate.  Medium boundaries
+ * keep their rects. */
+int rt_ctx_set_fuse_boxes(rt_ctx* ctx, int on);
+
 typedef struct rt_scene_info {
     uint64_t n_prims, n_nodes, n_groups, n_media;
     uint32_t max_depth;    /* deepest stack the traversal can need */

@@ -90,6 +90,7 @@ struct rt_ctx {
     uint64_t split_min_node_bytes = 256ull << 20;  // trees whose nodes outgrow the 256 MB Infinity Cache take the split pipeline
     int builder = -1;  // world-level BVH: -1 by size, 0 host (binned SAH), 1 device (linear BVH)
     uint64_t gpu_build_min = 1u << 18;  // builder -1: worlds with at least this many primitives are built on the device
+    bool fuse_boxes = true;  // six rects that form a Box2 become one box record at commit (env RTAMD_FUSE_BOXES=0: keep the rects)
     int bvh_width = -1;  // children per inner node the kernels walk: 2, 4 (four-child form made at commit), -1 by tree size
     uint64_t wide_min_nodes = 1u << 16;  // bvh_width -1: trees of at least this many nodes (4 MiB, one XCD's L2) are walked four-wide
     DevBuf d_wide;
@@ -154,6 +155,7 @@ bool is_device_ptr(const void* p) {
 struct PrimSrc {
     bool sphere;
     uint32_t idx;
+    bool box = false;  // rects idx .. idx+5 of the caller's arrays are the six sides of one Box2 (see fuse_boxes)
 };
 
 void sphere_box(const rt_ctx* c, uint32_t i, float t0, float t1, float lo[3], float hi[3]) {
@@ -190,6 +192,57 @@ void rect_box(const rt_ctx* c, uint32_t i, float lo[3], float hi[3]) {
     hi[a0] = std::max(b[0], b[2]);
     lo[a1] = std::min(b[1], b[3]);
     hi[a1] = std::max(b[1], b[3]);
+}
+void box_box(const rt_ctx* c, uint32_t i, float lo[3], float hi[3]) {
+    // union of the six side rects' boxes (each padded by 1e-4 on its thin axis, as above); the sides are stored
+    // XY(min.z), XY(max.z), XZ(min.y), XZ(max.y), YZ(min.x), YZ(max.x) with bounds (min0, min1, max0, max1)
+    const float* xy = &c->rect.bounds[4 * (size_t)i];
+    const float mn[3] = {xy[0], xy[1], c->rect.k[i]}, mx[3] = {xy[2], xy[3], c->rect.k[i + 1]};
+    for (int k = 0; k < 3; k++) {
+        lo[k] = std::min(mn[k], mx[k]) - 0.0001f;
+        hi[k] = std::max(mn[k], mx[k]) + 0.0001f;
+    }
+}
+// Is the run of six rects starting at s[0] exactly what Box2::full_box emits (shapes.rs:459-466)?  Consecutive
+// ids, one material, sides in the order XY(min.z), XY(max.z), XZ(min.y), XZ(max.y), YZ(min.x), YZ(max.x), and
+// every bound equal bit for bit to the corner it comes from.  Only then do six rect tests in this order with
+// these numbers equal the box record's.
+bool is_box2(const rt_ctx* c, const PrimSrc* s) {
+    const HostRects& r = c->rect;
+    for (int k = 0; k < 6; k++) {
+        if (s[k].sphere || s[k].box) return false;
+        if (r.id[s[k].idx] != r.id[s[0].idx] + (uint32_t)k || r.mat[s[k].idx] != r.mat[s[0].idx]) return false;
+        if (r.axis[s[k].idx] != (uint8_t)(k / 2)) return false;
+        if (s[k].idx != s[0].idx + (uint32_t)k) return false;  // the record reads k[i], k[i+1] and bounds[i] of the caller's arrays
+    }
+    const uint32_t i = s[0].idx;
+    const float* b = r.bounds.data();
+    auto same = [](float x, float y) { return memcmp(&x, &y, sizeof(float)) == 0; };
+    const float x0 = b[4 * i], y0 = b[4 * i + 1], x1 = b[4 * i + 2], y1 = b[4 * i + 3], z0 = r.k[i], z1 = r.k[i + 1];
+    const float want[6][5] = {{x0, y0, x1, y1, z0}, {x0, y0, x1, y1, z1}, {x0, z0, x1, z1, y0},
+                              {x0, z0, x1, z1, y1}, {y0, z0, y1, z1, x0}, {y0, z0, y1, z1, x1}};
+    for (int k = 0; k < 6; k++) {
+        for (int j = 0; j < 4; j++)
+            if (!same(b[4 * (i + k) + j], want[k][j])) return false;
+        if (!same(r.k[i + k], want[k][4])) return false;
+    }
+    return true;
+}
+// Replaces every run of six rects that is a Box2 by one box source (in place, order kept).
+void fuse_boxes(const rt_ctx* c, std::vector<PrimSrc>& v) {
+    std::vector<PrimSrc> out;
+    out.reserve(v.size());
+    for (size_t i = 0; i < v.size();) {
+        if (i + 6 <= v.size() && is_box2(c, &v[i])) {
+            PrimSrc s = v[i];
+            s.box = true;
+            out.push_back(s);
+            i += 6;
+        } else {
+            out.push_back(v[i++]);
+        }
+    }
+    v.swap(out);
 }
 // Boxes only cull; widen them a little so that rounding in the primitive tests (which follow the
 // reference's arithmetic exactly) can never place an accepted hit outside its leaf box.
@@ -232,6 +285,17 @@ rtd::Prim make_prim(const rt_ctx* c, const PrimSrc& s, std::vector<rtd::Moving>&
             p.aux = (uint32_t)moving.size();
             moving.push_back(m);
         }
+    } else if (s.box) {
+        const float* b = &c->rect.bounds[4 * (size_t)s.idx];  // side 0: XY rect (min.x, min.y, max.x, max.y) at z = min.z
+        p.a[0] = b[0];
+        p.a[1] = b[1];
+        p.a[2] = c->rect.k[s.idx];
+        p.a[3] = b[2];
+        p.b0 = b[3];
+        const float max_z = c->rect.k[s.idx + 1];
+        memcpy(&p.aux, &max_z, sizeof(float));
+        p.info = rtd::PK_BOX | (c->rect.mat[s.idx] << 8);
+        p.id = c->rect.id[s.idx];
     } else {
         const float* b = &c->rect.bounds[4 * (size_t)s.idx];
         p.a[0] = c->rect.k[s.idx];
@@ -368,6 +432,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
         const uint32_t w = env_u32("RTAMD_BVH_WIDTH", 0);
         c->bvh_width = w == 4 ? 4 : (w == 2 ? 2 : -1);
     }
+    if (getenv("RTAMD_FUSE_BOXES")) c->fuse_boxes = env_u32("RTAMD_FUSE_BOXES", 1) != 0;
     if (getenv("RTAMD_WIDE_MIN_NODES")) c->wide_min_nodes = env_u32("RTAMD_WIDE_MIN_NODES", 0);
     *out = c;
     return RT_OK;
@@ -417,6 +482,11 @@ int rt_ctx_set_builder(rt_ctx* c, int builder) {
 int rt_ctx_set_bvh_width(rt_ctx* c, int width) {
     if (!c || (width != 2 && width != 4 && width != -1)) return fail(c, RT_ERR_INVALID, "bvh width must be -1, 2 or 4");
     c->bvh_width = width;
+    return RT_OK;
+}
+int rt_ctx_set_fuse_boxes(rt_ctx* c, int on) {
+    if (!c) return RT_ERR_INVALID;
+    c->fuse_boxes = on != 0;
     return RT_OK;
 }
 int rt_ctx_reserve(rt_ctx* c, uint64_t n_paths) {
@@ -579,6 +649,12 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     for (uint32_t i = 0; i < c->rect.n; i++) members[c->rect.group[i]].push_back({false, i});
     auto id_of = [&](const PrimSrc& s) { return s.sphere ? c->sph.id[s.idx] : c->rect.id[s.idx]; };
     for (auto& v : members) std::sort(v.begin(), v.end(), [&](const PrimSrc& a, const PrimSrc& b) { return id_of(a) < id_of(b); });
+    // A Box2 (six rects, shapes.rs:456-466) becomes one record and one leaf: the tree over the world loses two to
+    // three levels where boxes dominate (final_scene: 2400 rects -> 400 boxes) and the six tests share three
+    // reciprocals.  Medium boundaries keep their rects (the boundary queries want the separate roots).
+    if (c->fuse_boxes)
+        for (uint32_t g = 0; g <= ng; g++)
+            if (g == 0 || c->groups[g - 1].kind != RT_GROUP_MEDIUM) fuse_boxes(c, members[g]);
 
     const uint32_t leaf_max = std::max(1u, std::min(env_u32("RTAMD_LEAF_MAX", 1), rtd::MAX_LEAF_PRIMS));
     std::vector<rtd::Node> nodes;
@@ -589,6 +665,8 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     auto prim_box = [&](const PrimSrc& s, float lo[3], float hi[3]) {
         if (s.sphere)
             sphere_box(c, s.idx, shutter_t0, shutter_t1, lo, hi);
+        else if (s.box)
+            box_box(c, s.idx, lo, hi);
         else
             rect_box(c, s.idx, lo, hi);
         widen(lo, hi);
@@ -619,7 +697,10 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         }
         D.order = G.kind == RT_GROUP_MEDIUM ? n_media++ : n_inst++;
         if (mem.empty()) continue;
-        if (mem.size() > 64) flat_ok = false;
+        // a box record costs six rect tests: size decisions count it as six
+        size_t mem_tests = 0;
+        for (const PrimSrc& ps : mem) mem_tests += ps.box ? 6 : 1;
+        if (mem_tests > 64) flat_ok = false;
         std::vector<rtb::Item> items(mem.size());
         float glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = 0; i < mem.size(); i++) {
@@ -635,7 +716,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         if (medium && mem.size() > rtd::MAX_LEAF_PRIMS)
             return fail(c, RT_ERR_UNSUPPORTED, "medium boundary with more than 16 primitives");
         if (medium && media_groups.size() >= 64) return fail(c, RT_ERR_UNSUPPORTED, "more than 64 media");
-        const bool single = medium || mem.size() <= 8;
+        const bool single = medium || mem_tests <= 8;
         std::vector<uint32_t> order;
         const uint32_t base = (uint32_t)prims.size();
         rtb::Result r = rtb::build(items, leaf_max, single, base, nodes, order);
@@ -703,7 +784,10 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
                 side[i] = 2.0f * std::fabs(a[3]);
             } else {
                 float lo[3], hi[3];
-                rect_box(c, world[i].idx, lo, hi);
+                if (world[i].box)
+                    box_box(c, world[i].idx, lo, hi);
+                else
+                    rect_box(c, world[i].idx, lo, hi);
                 side[i] = 0.0f;
                 for (int k = 0; k < 3; k++) {
                     ctr[k] = 0.5f * (lo[k] + hi[k]);

@@ -163,7 +163,7 @@ struct Hit {
     float t;
     uint32_t prim;  // index into prims[], HIT_NONE, or HIT_MEDIUM_BIT | group
     int grp;        // instance group of the hit primitive, or -1
-    uint32_t key;   // tie key: caller id of the primitive, MEDIUM_KEY_BASE + k for media
+    uint32_t key;   // tie key: caller id of the primitive (of the side that was hit, for a box), MEDIUM_KEY_BASE + k for media
 };
 
 DEV f3 moving_center(const Scene& S, f3 c0, uint32_t aux, float time) {  // shapes.rs:189-191
@@ -174,7 +174,47 @@ DEV f3 moving_center(const Scene& S, f3 c0, uint32_t aux, float time) {  // shap
     return c0 + (((time - t0) / (t1 - t0)) * (c1 - c0));
 }
 
+// One side of a box as the rect record it stands for (Box2::full_box, shapes.rs:459-466): sides 0,1 are the
+// XYRects at min.z / max.z, 2,3 the XZRects at min.y / max.y, 4,5 the YZRects at min.x / max.x; a rect record
+// is (k, min0, min1, max0 | max1).
+DEV void box_side_rect(float4 A, float4 B, uint32_t side, uint32_t& kind, float& k, float& min0, float& min1, float& max0, float& max1) {
+    const f3 lo{A.x, A.y, A.z}, hi{A.w, B.x, B.w};
+    const int ax = side < 2u ? 2 : (side < 4u ? 1 : 0);
+    const int a0 = ax == 0 ? 1 : 0, a1 = ax == 2 ? 1 : 2;
+    kind = side < 2u ? PK_RECT_XY : (side < 4u ? PK_RECT_XZ : PK_RECT_YZ);
+    k = (side & 1u) ? comp(hi, ax) : comp(lo, ax);
+    min0 = comp(lo, a0);
+    min1 = comp(lo, a1);
+    max0 = comp(hi, a0);
+    max1 = comp(hi, a1);
+}
+// (k0 - o) / d and (k1 - o) / d, the plane distances of two parallel sides (shapes.rs:280, 344, 408).  Both
+// quotients share the denominator, so they come from one refined reciprocal (bit-identical to the IEEE
+// division inside the window of div_by; a numerator that is tiny but not zero takes the plain division).
+DEV void plane_pair(float k0, float k1, float o, float d, float& t0, float& t1) {
+    const float n0 = k0 - o, n1 = k1 - o;
+    const float big = fmaxf(__builtin_fabsf(n0), __builtin_fabsf(n1));
+    const float small = fminf(n0 == 0.0f ? 1.0f : __builtin_fabsf(n0), n1 == 0.0f ? 1.0f : __builtin_fabsf(n1));
+    if (in_div_window(d) && big < 0x1p60f && small > 0x1p-60f) {
+        const float r = recip_refined(d);
+        t0 = div_by(n0, d, r);
+        t1 = div_by(n1, d, r);
+    } else {
+        t0 = n0 / d;
+        t1 = n1 / d;
+    }
+}
+// One rect side inside Scene::intersect over the box's sides (scene.rs:27-41): accepted when t lies in
+// [tmin, closest] and the in-plane point inside the bounds, all inclusive; a later side with the same t wins.
+DEV void box_side(float t, float p0, float p1, float min0, float min1, float max0, float max1, float tmin, uint32_t s, float& closest,
+                  uint32_t& side) {
+    if (t < tmin || t > closest) return;
+    if (p0 < min0 || p0 > max0 || p1 < min1 || p1 > max1) return;
+    closest = t;
+    side = s;
+}
 // Candidate t of one primitive in [tmin, tmax] (inclusive, as the reference's "< t_min || > t_max" rejects).
+// id_out: the caller's id of the primitive that was hit -- for a box, of the side that won.
 DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out,
                         uint32_t& id_out) {
     const float4* pp = reinterpret_cast<const float4*>(S.prims + pi);
@@ -199,6 +239,23 @@ DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float 
             t = (-half_b + sq) / a;
             if (t < tmin || t > tmax) return false;
         }
+    } else if (kind == PK_BOX) {  // Box2::intersect = Scene::intersect over the six sides (shapes.rs:474-477)
+        const f3 lo{A.x, A.y, A.z}, hi{A.w, B.x, B.w};
+        float tz0, tz1, ty0, ty1, tx0, tx1;
+        plane_pair(lo.z, hi.z, o.z, d.z, tz0, tz1);
+        plane_pair(lo.y, hi.y, o.y, d.y, ty0, ty1);
+        plane_pair(lo.x, hi.x, o.x, d.x, tx0, tx1);
+        float closest = tmax;
+        uint32_t side = 6u;
+        box_side(tz0, o.x + tz0 * d.x, o.y + tz0 * d.y, lo.x, lo.y, hi.x, hi.y, tmin, 0u, closest, side);
+        box_side(tz1, o.x + tz1 * d.x, o.y + tz1 * d.y, lo.x, lo.y, hi.x, hi.y, tmin, 1u, closest, side);
+        box_side(ty0, o.x + ty0 * d.x, o.z + ty0 * d.z, lo.x, lo.z, hi.x, hi.z, tmin, 2u, closest, side);
+        box_side(ty1, o.x + ty1 * d.x, o.z + ty1 * d.z, lo.x, lo.z, hi.x, hi.z, tmin, 3u, closest, side);
+        box_side(tx0, o.y + tx0 * d.y, o.z + tx0 * d.z, lo.y, lo.z, hi.y, hi.z, tmin, 4u, closest, side);
+        box_side(tx1, o.y + tx1 * d.y, o.z + tx1 * d.z, lo.y, lo.z, hi.y, hi.z, tmin, 5u, closest, side);
+        if (side == 6u) return false;
+        t = closest;
+        id_out += side;
     } else {  // shapes.rs:279-292, 343-356, 407-420
         int ax = kind == PK_RECT_XY ? 2 : (kind == PK_RECT_XZ ? 1 : 0);
         int a0 = ax == 0 ? 1 : 0;
@@ -669,6 +726,12 @@ DEV void make_record(const Scene& S, const LdsTables& L, f3 wo, f3 wd, float tim
     uint32_t info = __float_as_uint(B.y);
     uint32_t kind = info & 7u;
     rec.mat = info >> 8;
+    if (kind == PK_BOX) {  // the side that was hit, as the rect it stands for (Hit::key is its id)
+        float k, min0, min1, max0, max1;
+        box_side_rect(A, B, h.key - __float_as_uint(B.z), kind, k, min0, min1, max0, max1);
+        A = make_float4(k, min0, min1, max0);
+        B.x = max1;
+    }
     f3 point = o + (h.t * d);
     f3 outward;
     rec.u = 0.0f;

@@ -26,14 +26,17 @@ constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 constexpr uint32_t HIT_MEDIUM_BIT = 0x80000000u;  // hit.prim = HIT_MEDIUM_BIT | group index
 constexpr uint32_t MEDIUM_KEY_BASE = 0x40000000u; // tie key of the k-th medium
 
-enum PrimKind : uint32_t { PK_SPHERE = 0, PK_MOVING_SPHERE = 1, PK_RECT_XY = 2, PK_RECT_XZ = 3, PK_RECT_YZ = 4 };
+// PK_BOX: the six rects of a Box2 (shapes.rs:456-466) kept as ONE record and one BVH leaf.  The kernels still
+// evaluate the six rect tests in the reference's side order with the reference's arithmetic, so hits, ids and
+// ties are those of six separate rects; what changes is the tree (one leaf instead of six).
+enum PrimKind : uint32_t { PK_SPHERE = 0, PK_MOVING_SPHERE = 1, PK_RECT_XY = 2, PK_RECT_XZ = 3, PK_RECT_YZ = 4, PK_BOX = 5 };
 
 struct alignas(32) Prim {
-    float a[4];     // sphere: cx,cy,cz,r        rect: k, min0, min1, max0
-    float b0;       // sphere: unused            rect: max1
+    float a[4];     // sphere: cx,cy,cz,r        rect: k, min0, min1, max0       box: min.x, min.y, min.z, max.x
+    float b0;       // sphere: unused            rect: max1                      box: max.y
     uint32_t info;  // bits 2..0 PrimKind, bits 31..8 material index
-    uint32_t id;    // caller's flat id (tie key, reported by rt_intersect_batch)
-    uint32_t aux;   // moving sphere: index into moving[]
+    uint32_t id;    // caller's flat id (tie key, reported by rt_intersect_batch); box: id of its first side
+    uint32_t aux;   // moving sphere: index into moving[]                        box: bits of max.z
 };
 static_assert(sizeof(Prim) == 32, "Prim must be 32 B");
 

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
             const float4 ot = in.o_time[at], ds = in.d_slot[at];
             Hit h;
             trace_flat<GROUPS, COUNT>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, h, &tc);
-            hits[at] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), 0.0f);
+            hits[at] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), __uint_as_float(h.key));
         }
         if (COUNT) {
             if (tc.prims) atomicAdd(stats + 2, (unsigned long long)tc.prims);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
             walk_inner<rtk::BLOCK, COUNT>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
             walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, wo, wd, time, 0.005f, stk, overflow_flag, &tc);
             if (walk_done(w)) {
-                hits[idx] = make_float4(w.best.t, __uint_as_float(w.best.prim), __int_as_float(w.best.grp), 0.0f);
+                hits[idx] = make_float4(w.best.t, __uint_as_float(w.best.prim), __int_as_float(w.best.grp), __uint_as_float(w.best.key));
                 have = false;
             }
         }
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             h.t = hv.x;
             h.prim = __float_as_uint(hv.y);
             h.grp = __float_as_int(hv.z);
-            h.key = 0;
+            h.key = __float_as_uint(hv.w);
             if (S.n_media) apply_media<false>(S, p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h, nullptr);
             alive = shade_path(S, L, rc, p, h, bounce, radiance);
         }
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
                 if (h.prim & HIT_MEDIUM_BIT)
                     id = -(int32_t)(S.groups[h.prim & 0x3FFFFFFFu].order + 2u);
                 else
-                    id = (int32_t)S.prims[h.prim].id;
+                    id = (int32_t)h.key;  // the primitive's id; for a box, the id of the side that was hit
             }
             prim[i] = id;
         }

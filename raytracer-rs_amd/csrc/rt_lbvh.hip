@@ -53,6 +53,13 @@ __device__ Box3 prim_box(const rtd::Prim& p, const rtd::Moving* moving, float t0
                 }
             }
         }
+    } else if (kind == rtd::PK_BOX) {
+        // union of the six side rects' boxes: every side is padded by 1e-4 on its thin axis
+        const float mn[3] = {p.a[0], p.a[1], p.a[2]}, mx[3] = {p.a[3], p.b0, __uint_as_float(p.aux)};
+        for (int k = 0; k < 3; k++) {
+            b.lo[k] = fminf(mn[k], mx[k]) - 0.0001f;
+            b.hi[k] = fmaxf(mn[k], mx[k]) + 0.0001f;
+        }
     } else {
         const int ax = kind == rtd::PK_RECT_XY ? 2 : (kind == rtd::PK_RECT_XZ ? 1 : 0);
         const int a0 = ax == 0 ? 1 : 0, a1 = ax == 2 ? 1 : 2;

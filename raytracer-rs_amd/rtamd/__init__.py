@@ -29,7 +29,7 @@ STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPP
 # every symbol include/rtamd.h declares
 ABI_SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_ctx_set_stream", "rt_ctx_set_max_paths",
-    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_reserve", "rt_ctx_set_builder", "rt_ctx_set_bvh_width", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
+    "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_reserve", "rt_ctx_set_builder", "rt_ctx_set_bvh_width", "rt_ctx_set_fuse_boxes", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
     "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_accum_write", "rt_accum_read", "rt_accum_write_tagged",
@@ -126,6 +126,7 @@ def core():
     L.rt_ctx_reserve.argtypes = [vp, u64]
     L.rt_ctx_set_builder.argtypes = [vp, C.c_int]
     L.rt_ctx_set_bvh_width.argtypes = [vp, C.c_int]
+    L.rt_ctx_set_fuse_boxes.argtypes = [vp, C.c_int]
     L.rt_scene_read_bvh.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u32)]
     L.rt_scene_clear.argtypes = [vp]
     L.rt_scene_set_spheres.argtypes = [vp, u32] + [vp] * 7
@@ -349,6 +350,10 @@ class Context:
     def set_bvh_width(self, width):
         """Children per inner node the kernels walk from the next commit on: 2, 4, or -1 = by tree size (same hits either way)."""
         self._check(self.L.rt_ctx_set_bvh_width(self.h, width))
+
+    def set_fuse_boxes(self, on):
+        """From the next commit on: keep the six rects of a Box2 as one record and leaf (default) or as six rects (same hits)."""
+        self._check(self.L.rt_ctx_set_fuse_boxes(self.h, 1 if on else 0))
 
     def set_builder(self, builder):
         """World-level BVH builder of the next commit: -1 by size, 0 host (binned SAH), 1 device (linear BVH)."""
