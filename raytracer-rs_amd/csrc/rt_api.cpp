@@ -1314,6 +1314,15 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 fprintf(stderr, "[rtamd] wave cycles per tile: fetch/raygen %.0f  trace %.0f  shade %.0f  compact %.0f  (tiles %llu)\n",
                         h[3] / (double)h[7], h[4] / (double)h[7], h[5] / (double)h[7], h[6] / (double)h[7], h[7]);
         }
+        if (c->count_visits && getenv("RTAMD_TRACE_LANES") && c->h_rays[12]) {
+            // instrumented persistent trace kernel: how full its waves were
+            const unsigned long long* h = c->h_rays;
+            fprintf(stderr,
+                    "[rtamd] k_trace lanes: rounds %llu, lanes holding a ray %.1f/64 | inner steps %llu at %.1f lanes | leaf steps %llu at %.1f lanes "
+                    "| per round %.2f inner + %.2f leaf steps | non-finite rays %llu\n",
+                    h[12], h[13] / (double)h[12], h[9], h[14] / (double)std::max(1ull, h[9]), h[10], h[11] / (double)std::max(1ull, h[10]),
+                    h[9] / (double)h[12], h[10] / (double)h[12], h[15]);
+        }
         if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     }
     if (c->profile) {

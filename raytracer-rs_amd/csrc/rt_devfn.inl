@@ -154,6 +154,9 @@ DEV f3 rand_in_unit_sphere(Rng& r) {  // vec3_helpers.rs:25-31
     for (;;) {
         float x = r.range_pm1(), y = r.range_pm1(), z = r.range_pm1();
         f3 p{x, y, z};
+#ifdef EXP_ONE_TRY
+        return p;
+#endif
         if (!(dot3(p, p) >= 1.0f)) return p;
     }
 }
@@ -242,15 +245,15 @@ DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float 
     } else if (kind == PK_BOX) {  // Box2::intersect = Scene::intersect over the six sides (shapes.rs:474-477)
         const f3 lo{A.x, A.y, A.z}, hi{A.w, B.x, B.w};
         float tz0, tz1, ty0, ty1, tx0, tx1;
-        plane_pair(lo.z, hi.z, o.z, d.z, tz0, tz1);
-        plane_pair(lo.y, hi.y, o.y, d.y, ty0, ty1);
-        plane_pair(lo.x, hi.x, o.x, d.x, tx0, tx1);
         float closest = tmax;
         uint32_t side = 6u;
+        plane_pair(lo.z, hi.z, o.z, d.z, tz0, tz1);
         box_side(tz0, o.x + tz0 * d.x, o.y + tz0 * d.y, lo.x, lo.y, hi.x, hi.y, tmin, 0u, closest, side);
         box_side(tz1, o.x + tz1 * d.x, o.y + tz1 * d.y, lo.x, lo.y, hi.x, hi.y, tmin, 1u, closest, side);
+        plane_pair(lo.y, hi.y, o.y, d.y, ty0, ty1);
         box_side(ty0, o.x + ty0 * d.x, o.z + ty0 * d.z, lo.x, lo.z, hi.x, hi.z, tmin, 2u, closest, side);
         box_side(ty1, o.x + ty1 * d.x, o.z + ty1 * d.z, lo.x, lo.z, hi.x, hi.z, tmin, 3u, closest, side);
+        plane_pair(lo.x, hi.x, o.x, d.x, tx0, tx1);
         box_side(tx0, o.y + tx0 * d.y, o.z + tx0 * d.z, lo.y, lo.z, hi.y, hi.z, tmin, 4u, closest, side);
         box_side(tx1, o.y + tx1 * d.y, o.z + tx1 * d.z, lo.y, lo.z, hi.y, hi.z, tmin, 5u, closest, side);
         if (side == 6u) return false;
@@ -407,7 +410,11 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     double len = (double)len3(wd);
     double inside = (double)(r2 - r1) / len;
     double xi = medium_xi(k0, k1, bounce, G.order);
+#ifdef EXP_F32_LOG
+    double hit_distance = G.neg_inv_density * (double)__logf((float)xi);
+#else
     double hit_distance = G.neg_inv_density * log(xi);
+#endif
     if (hit_distance > inside) return;
     best.t = r1 + (float)(hit_distance / len);
     best.prim = HIT_MEDIUM_BIT | g;
@@ -449,37 +456,84 @@ DEV void stack_put(const Stack& st, int sp, uint32_t v) {
     else
         st.spill[(size_t)((uint32_t)sp - st.lds_cap) * st.spill_stride] = v;
 }
+// (The LDS read is issued unconditionally, at a clamped index, and the rare spilled entry replaces its value: a
+// select between an LDS and a global ADDRESS would turn every pop into a flat load.)
 template <int STRIDE>
 DEV uint32_t stack_get(const Stack& st, int sp) {
-    if ((uint32_t)sp < st.lds_cap) return st.lds[sp * STRIDE];
-    return st.spill[(size_t)((uint32_t)sp - st.lds_cap) * st.spill_stride];
+    const uint32_t at = (uint32_t)sp < st.lds_cap ? (uint32_t)sp : 0u;
+    uint32_t v = st.lds[at * STRIDE];
+    if ((uint32_t)sp >= st.lds_cap) v = st.spill[(size_t)((uint32_t)sp - st.lds_cap) * st.spill_stride];
+    return v;
 }
 // Short-stack traversal of the two-level BVH.  stk points at this lane's column of the LDS stack;
 // consecutive entries are STRIDE words apart so that the 64 lanes of a wave hit 64 different banks.
+DEV uint32_t lane_prefix(unsigned long long mask);
 struct TraceCount {
     uint32_t nodes, prims;  // inner nodes fetched, primitive records tested (instrumented builds only)
+    // lane use of the walk: wave-level executions of an inner step / a leaf step (counted by the first active
+    // lane) against the lanes that took part (nodes for inner steps, leaf_lanes for leaf steps)
+    uint32_t inner_waves, leaf_waves, leaf_lanes;
 };
+DEV bool first_active_lane() { return lane_prefix(__ballot(true)) == 0u; }
 // Traversal state of one ray.  cur == REF_EMPTY with sp == 0 means the walk is over.
 struct Walk {
     uint32_t cur;
     int sp;
-    f3 o, d, inv;  // the ray in the space of the subtree being walked (world, or an instance's object space)
-    float a;       // |d|^2
-    int grp;       // instance being walked, or -1
+    f3 o, d;         // the ray in the space of the subtree being walked (world, or an instance's object space)
+    f3 inv;          // 1/d (fast reciprocal, clamped to +-1e30)
+    f3 oi_n, oi_f;   // -(o * inv) lowered / raised by its own rounding slack: see walk_set_ray
+    float a;         // |d|^2
+    int grp;         // instance being walked, or -1
     Hit best;
 };
+// Box tests only cull, so a plane distance (plane - o) / d is evaluated as ONE fma(plane, inv, oi), oi = -(o * inv).
+// With inv within 1 ulp of 1/d and oi rounded once, the result is off by at most 2e-7 * |t| plus 6e-8 * |o * inv| of
+// that axis.  The second part is folded into the constant: the near plane of an axis (the lower one when inv >= 0)
+// uses oi_n = oi - 1.2e-7 * |oi|, the far plane oi_f = oi + 1.2e-7 * |oi|; the first part is the 6e-7 * |t| padding
+// of slab_fma.  So a box the exact ray touches is never culled, per axis, however small a direction component is.
+// A zero component has inv = +-1e30 (clamped) and culls like any other; where a product still overflows, the
+// distance is inf or NaN and v_min/v_max/compare are used so that NaN means "no constraint" / "visit".
+DEV void walk_set_ray(Walk& w, f3 o, f3 d) {
+    w.o = o;
+    w.d = d;
+    w.a = dot3(d, d);
+    const f3 r = fast_rcp3(d);
+    w.inv = {__builtin_amdgcn_fmed3f(r.x, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(r.y, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(r.z, -1e30f, 1e30f)};
+    const f3 oi{-(o.x * w.inv.x), -(o.y * w.inv.y), -(o.z * w.inv.z)};
+    const f3 e{__builtin_fabsf(oi.x) * 1.2e-7f, __builtin_fabsf(oi.y) * 1.2e-7f, __builtin_fabsf(oi.z) * 1.2e-7f};
+    w.oi_n = oi - e;
+    w.oi_f = oi + e;
+}
 DEV void walk_begin(const Scene& S, Walk& w, f3 wo, f3 wd, float tmax) {
     w.best.t = tmax;
     w.best.prim = HIT_NONE;
     w.best.grp = -1;
     w.best.key = 0;
     w.cur = S.root_ref;
-    w.o = wo;
-    w.d = wd;
-    w.a = dot3(wd, wd);
-    w.inv = fast_rcp3(wd);
+    walk_set_ray(w, wo, wd);
     w.grp = -1;
     w.sp = 0;
+    // A ray with a NaN or infinite component (one path in ~10^8 produces one) has no defined closest hit: every
+    // comparison of the reference's tests is false for it, so each primitive "hits" and the last one visited
+    // wins -- whichever that is in the reference's random tree.  Here such a ray misses the tree: nothing is
+    // walked (with all box tests passing it would visit every node, bounce after bounce).
+    const float chk = ((wo.x + wo.y) + wo.z) + ((wd.x + wd.y) + wd.z);
+    if (!(__builtin_fabsf(chk) < INF_F)) w.cur = REF_EMPTY;
+}
+// Conservative slab test of the walk: entry distance in tn; false only when the box certainly holds no hit in
+// [tmin, tbest].  The near plane of each axis is picked by the sign of inv (one select instead of a min and a max).
+DEV bool slab_fma(f3 lo, f3 hi, const Walk& w, float tmin, float tbest, float& tn) {
+    const bool px = w.inv.x >= 0.0f, py = w.inv.y >= 0.0f, pz = w.inv.z >= 0.0f;
+    const float nx = __builtin_fmaf(px ? lo.x : hi.x, w.inv.x, w.oi_n.x), fx = __builtin_fmaf(px ? hi.x : lo.x, w.inv.x, w.oi_f.x);
+    const float ny = __builtin_fmaf(py ? lo.y : hi.y, w.inv.y, w.oi_n.y), fy = __builtin_fmaf(py ? hi.y : lo.y, w.inv.y, w.oi_f.y);
+    const float nz = __builtin_fmaf(pz ? lo.z : hi.z, w.inv.z, w.oi_n.z), fz = __builtin_fmaf(pz ? hi.z : lo.z, w.inv.z, w.oi_f.z);
+    const float n = fmaxf(fmaxf(nx, ny), nz);
+    const float f = fminf(fminf(fx, fy), fz);
+    tn = n;
+    const float np = __builtin_fmaf(-__builtin_fabsf(n), 6e-7f, n);
+    const float fp = __builtin_fmaf(__builtin_fabsf(f), 6e-7f, f);
+    const bool miss = (np > fp) || (fp < tmin) || (np > tbest);
+    return !miss;
 }
 DEV bool walk_done(const Walk& w) { return w.cur == REF_EMPTY; }
 // Walks inner nodes only (at most max_steps of them), until cur is a leaf, an instance, a sentinel or empty.
@@ -498,18 +552,20 @@ DEV void near_first(float& ka, uint32_t& ra, float& kb, uint32_t& rb) {
 // dependent fetches per ray.  The children that are hit are entered nearest first; the others wait on the stack,
 // the farthest at the bottom.  Every valid tree gives the same closest hit, so the result equals the binary walk's.
 template <int STRIDE, bool COUNT>
-DEV void walk_inner_wide(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt,
-                         int max_steps) {
-    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) {
+DEV void inner_step_wide(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt) {
+    {
         const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
         const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
-        if (COUNT) cnt->nodes++;
+        if (COUNT) {
+            cnt->nodes++;
+            if (first_active_lane()) cnt->inner_waves++;
+        }
         float k0, k1, k2, k3;
         uint32_t r0 = __float_as_uint(q6.x), r1 = __float_as_uint(q6.y), r2 = __float_as_uint(q6.z), r3 = __float_as_uint(q6.w);
-        const bool h0 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), w.o, w.inv, tmin, w.best.t, k0) && r0 != REF_EMPTY;
-        const bool h1 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), w.o, w.inv, tmin, w.best.t, k1) && r1 != REF_EMPTY;
-        const bool h2 = slab(mk3(q3.x, q3.y, q3.z), mk3(q3.w, q4.x, q4.y), w.o, w.inv, tmin, w.best.t, k2) && r2 != REF_EMPTY;
-        const bool h3 = slab(mk3(q4.z, q4.w, q5.x), mk3(q5.y, q5.z, q5.w), w.o, w.inv, tmin, w.best.t, k3) && r3 != REF_EMPTY;
+        const bool h0 = slab_fma(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), w, tmin, w.best.t, k0) && r0 != REF_EMPTY;
+        const bool h1 = slab_fma(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), w, tmin, w.best.t, k1) && r1 != REF_EMPTY;
+        const bool h2 = slab_fma(mk3(q3.x, q3.y, q3.z), mk3(q3.w, q4.x, q4.y), w, tmin, w.best.t, k2) && r2 != REF_EMPTY;
+        const bool h3 = slab_fma(mk3(q4.z, q4.w, q5.x), mk3(q5.y, q5.z, q5.w), w, tmin, w.best.t, k3) && r3 != REF_EMPTY;
         // a box that is hit has a finite entry distance (or -inf), so +inf sorts the misses behind every hit
         k0 = h0 ? k0 : INF_F;
         k1 = h1 ? k1 : INF_F;
@@ -545,39 +601,45 @@ DEV void walk_inner_wide(const Scene& S, Walk& w, float tmin, const Stack& stk, 
     }
 }
 template <int STRIDE, bool COUNT>
-DEV void walk_inner(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
+DEV void inner_step(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt) {
     if (S.wide) {  // (the same in every lane)
-        walk_inner_wide<STRIDE, COUNT>(S, w, tmin, stk, overflow_flag, cnt, max_steps);
+        inner_step_wide<STRIDE, COUNT>(S, w, tmin, stk, overflow_flag, cnt);
         return;
     }
-    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) {
-        const float4* np = reinterpret_cast<const float4*>(S.nodes + w.cur);
-        float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-        if (COUNT) cnt->nodes++;
-        float tn0, tn1;
-        bool h0 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), w.o, w.inv, tmin, w.best.t, tn0);
-        bool h1 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), w.o, w.inv, tmin, w.best.t, tn1);
-        uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-        h0 = h0 && (c0 != REF_EMPTY);
-        h1 = h1 && (c1 != REF_EMPTY);
-        if (h0 || h1) {
-            bool first1 = h1 && (!h0 || tn1 < tn0);
-            w.cur = first1 ? c1 : c0;
-            if (h0 && h1) {
-                if (w.sp < (int)S.stack_cap) {
-                    stack_put<STRIDE>(stk, w.sp, first1 ? c0 : c1);
-                    w.sp++;
-                } else {
-                    *overflow_flag = 1u;
-                }
-            }
-        } else if (w.sp > 0) {
-            w.sp--;
-            w.cur = stack_get<STRIDE>(stk, w.sp);
-        } else {
-            w.cur = REF_EMPTY;
-        }
+    const float4* np = reinterpret_cast<const float4*>(S.nodes + w.cur);
+    float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    if (COUNT) {
+        cnt->nodes++;
+        if (first_active_lane()) cnt->inner_waves++;
     }
+    float tn0, tn1;
+    bool h0 = slab_fma(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), w, tmin, w.best.t, tn0);
+    bool h1 = slab_fma(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), w, tmin, w.best.t, tn1);
+    uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+    h0 = h0 && (c0 != REF_EMPTY);
+    h1 = h1 && (c1 != REF_EMPTY);
+    if (h0 || h1) {
+        bool first1 = h1 && (!h0 || tn1 < tn0);
+        w.cur = first1 ? c1 : c0;
+        if (h0 && h1) {
+            if (w.sp < (int)S.stack_cap) {
+                stack_put<STRIDE>(stk, w.sp, first1 ? c0 : c1);
+                w.sp++;
+            } else {
+                *overflow_flag = 1u;
+            }
+        }
+    } else if (w.sp > 0) {
+        w.sp--;
+        w.cur = stack_get<STRIDE>(stk, w.sp);
+    } else {
+        w.cur = REF_EMPTY;
+    }
+}
+// Walks inner nodes only (at most max_steps of them), until cur is a leaf, an instance, a sentinel or empty.
+template <int STRIDE, bool COUNT>
+DEV void walk_inner(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
+    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) inner_step<STRIDE, COUNT>(S, w, tmin, stk, overflow_flag, cnt);
 }
 // One non-inner step: tests a leaf's primitives, enters an instance or leaves it, then takes the next entry
 // from the stack.  No-op when cur is an inner node or empty.
@@ -586,6 +648,10 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
                    TraceCount* cnt) {
     const uint32_t type = w.cur >> 30;
     if (w.cur == REF_EMPTY || type == REF_INNER) return;
+    if (COUNT) {
+        cnt->leaf_lanes++;
+        if (first_active_lane()) cnt->leaf_waves++;
+    }
     if (type == REF_PRIMS) {
         uint32_t first = w.cur & 0x03FFFFFFu, n_leaf = ((w.cur >> 26) & 15u) + 1u;
         for (uint32_t i = 0; i < n_leaf; i++) test_prim(S, first + i, w.o, w.d, w.a, time, tmin, w.grp, w.best);
@@ -598,12 +664,7 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
         w.cur = REF_EMPTY;
         if (root != REF_EMPTY) {
             if (w.sp < (int)S.stack_cap) {
-                if (G.has_xform) {  // shapes.rs:66-70
-                    w.o = xf_point(G.minv, wo);
-                    w.d = xf_vector(G.minv, wd);
-                    w.a = dot3(w.d, w.d);
-                    w.inv = fast_rcp3(w.d);
-                }
+                if (G.has_xform) walk_set_ray(w, xf_point(G.minv, wo), xf_vector(G.minv, wd));  // shapes.rs:66-70
                 stack_put<STRIDE>(stk, w.sp, REF_SENTINEL);
                 w.sp++;
                 w.grp = (int)g;
@@ -613,10 +674,7 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
             }
         }
     } else {  // REF_SENTINEL: the instance's subtree is finished, back to the world ray
-        w.o = wo;
-        w.d = wd;
-        w.a = dot3(wd, wd);
-        w.inv = fast_rcp3(wd);
+        walk_set_ray(w, wo, wd);
         w.grp = -1;
         w.cur = REF_EMPTY;
     }
@@ -631,6 +689,9 @@ template <bool COUNT>
 DEV void apply_media(const Scene& S, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce, Hit& best,
                      TraceCount* cnt) {
     for (uint32_t m = 0; m < S.n_media; m++) {
+#ifdef EXP_NO_MEDIA
+        continue;
+#endif
         test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
         if (COUNT) cnt->prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);  // two boundary queries
     }
@@ -862,6 +923,9 @@ DEV f3 tex_value(const Scene& S, const LdsTables& L, uint32_t ti, float u, float
     if (kind == TK_NOISE) {  // texture.rs:78-82
         const uint32_t table = __float_as_uint(T1.w);
         float turb;
+#ifdef EXP_NO_NOISE
+        return {0.5f, 0.5f, 0.5f};
+#endif
         if (L.has_perlin0 && table == 0u)
             turb = perlin_turb(*L.perlin0, p, 7);
         else

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
     }
     const Stack stk{stack + threadIdx.x, S.stack_cap, nullptr, 0u};
     const LdsTables L = stage_tables(S, stack);
-    TraceCount tc{0u, 0u};
+    TraceCount tc{0u, 0u, 0u, 0u, 0u};
     uint32_t parity = 0;
     // instrumented build only: wave cycles spent per section (s_memtime ticks), and wave tiles
     unsigned long long cyc[4] = {0, 0, 0, 0}, tiles = 0, t0 = 0, t1 = 0;
@@ -312,8 +312,11 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
     }
 }
 
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 5
+#endif
 template <bool GROUPS, bool COUNT>
-__global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
+__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES))) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
                                                        uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS, uint32_t lds_entries,
                                                        uint32_t* spill) {
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
     }
     // blockIdx.x * BLOCK + threadIdx.x is this thread's column of the spill area (gridDim.x * BLOCK columns)
     const Stack stk{stack + threadIdx.x, lds_entries, spill + (size_t)blockIdx.x * rtk::BLOCK + threadIdx.x, gridDim.x * (uint32_t)rtk::BLOCK};
-    TraceCount tc{0u, 0u};
+    TraceCount tc{0u, 0u, 0u, 0u, 0u};
     if (S.flat) {  // no tree, no divergence between rays: plain strided loop
         for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
             const uint32_t at = shard_base + i;
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
     uint32_t media_prims = 0;
     if (COUNT && GROUPS)
         for (uint32_t m = 0; m < S.n_media; m++) media_prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);
+    uint32_t rounds = 0, busy_lanes = 0;  // instrumented build: loop rounds of this wave and the lanes that held a ray in them
     for (;;) {
         const unsigned long long idle = __ballot(!have);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -375,8 +379,16 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
                 time = ot.w;
                 walk_begin(S, w, wo, wd, INF_F);
                 have = true;
-                if (COUNT) tc.prims += media_prims;
+                if (COUNT) {
+                    tc.prims += media_prims;
+                    const float chk = ((wo.x + wo.y) + wo.z) + ((wd.x + wd.y) + wd.z);
+                    if (!(__builtin_fabsf(chk) < INF_F)) atomicAdd(stats + 15, 1ull);  // rays with a NaN or infinite component
+                }
             }
+        }
+        if (COUNT) {
+            if ((threadIdx.x & 63u) == 0u) rounds++;
+            if (have) busy_lanes++;
         }
         if (have) {
             walk_inner<rtk::BLOCK, COUNT>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
@@ -390,6 +402,13 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_trace(Scene S, rtk::PathState in
     if (COUNT) {
         if (tc.nodes) atomicAdd(stats + 1, (unsigned long long)tc.nodes);
         if (tc.prims) atomicAdd(stats + 2, (unsigned long long)tc.prims);
+        // lane use of the persistent walk (words 9..14; read with RTAMD_TRACE_LANES set)
+        if (tc.inner_waves) atomicAdd(stats + 9, (unsigned long long)tc.inner_waves);
+        if (tc.leaf_waves) atomicAdd(stats + 10, (unsigned long long)tc.leaf_waves);
+        if (tc.leaf_lanes) atomicAdd(stats + 11, (unsigned long long)tc.leaf_lanes);
+        if (rounds) atomicAdd(stats + 12, (unsigned long long)rounds);
+        if (busy_lanes) atomicAdd(stats + 13, (unsigned long long)busy_lanes);
+        if (tc.nodes) atomicAdd(stats + 14, (unsigned long long)tc.nodes);
     }
 }
 
