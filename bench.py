@@ -6,6 +6,11 @@ sample count, the frame's tiles dealt round-robin over the ranks, each rank's ti
 the complete frame on every rank with one all_gather (RCCL over xGMI) per frame.  Inputs (scene,
 BVH, textures, pixel lists) are resident in HBM before the timed region starts.
 
+The default workload is the scene the reference binary itself renders (main.rs:353-354, 375-380):
+the Next Week final scene, 800x800, 10 000 samples per pixel, depth 50 -- the tree-walking path
+(BVHNode::intersect) the metric is about.  With one rank the same run also renders one frame each
+of BASELINE.json's configs[0..2] outside the timed steps and lists them under config.others.
+
   python bench.py                       # 1 GPU, default steps
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
          --master-port P bench.py --gpus N --steps K --warmup W
@@ -41,13 +46,16 @@ WORKLOADS = {
     "c3_random_world": (("random_world",), 1920, 16.0 / 9.0, 1024),
     # configs[3]: Cornell box + constant-medium volumes, 2048x2048, 4096 spp
     "c4_cornell": (("cornell_box", "cornell_smoke"), 2048, 1.0, 4096),
-    # the north star's target scene: Next Week final scene, 800x800 (spp reduced from the binary's 10000)
-    "final_scene": (("final_scene",), 800, 1.0, 256),
+    # the north star's target scene at the reference binary's own preset (main.rs:375-380): 800x800, 10 000 spp
+    "final_scene": (("final_scene",), 800, 1.0, 10000),
     # configs[4]: synthetic 10M-sphere scene, 3840x2160, 1024 spp
     "c5_synth10m": (("synth_spheres",), 3840, 16.0 / 9.0, 1024),
 }
 MAX_DEPTH = 50
 PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak
+DEFAULT_WORKLOAD = "final_scene"
+# one frame each, outside the timed steps, when the default workload runs on one rank
+OTHER_CONFIGS = ("c1_random_world", "c2_textures", "c3_random_world")
 
 
 def log(*a):
@@ -140,49 +148,197 @@ def bounce_bytes_per_ray(info, primary_frac, alive_frac, nodes_per_ray, prims_pe
 
 
 def measured_traffic(workload, kernel):
-    """HBM bytes per step of the dominant kernel from the newest committed PMC summary of this workload
+    """(HBM bytes, file, launches) of a kernel over the profiled run, from the newest committed PMC summary of this workload
     (profiles/*_<workload>_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc
     passes of this script, the read side doubled as gfx950 needs).  None when no summary matches."""
     best = None
-    for f in sorted((ROOT / "profiles").glob(f"*_{workload}_hbm_traffic.json")):
+    for f in sorted((ROOT / "profiles").glob(f"*_{workload}*_hbm_traffic.json")):
         try:
             doc = json.loads(f.read_text())
         except (OSError, ValueError):
             continue
         if doc.get("kernel", "").startswith(kernel) and doc.get("bytes_per_step"):
-            best = (doc["bytes_per_step"], f.name)
+            launches = max(doc.get("dispatches_fetch_pass", 0), 1)
+            best = (doc["read_bytes"] + doc["write_bytes"], f.name, launches)
     return best
 
 
-def cpu_baseline(frames_cfg, width, aspect, seconds_target=15.0):
-    """The CPU oracle (a port of the reference; the Rust binary cannot be built here) on a bounded
-    sample of the same workload: the same frames at full resolution and reduced spp, reference-style
-    pointer BVH, all host threads the box share allows."""
+def host_threads():
+    """CPU threads this process may use: its affinity mask (the box's CPU share; os.cpu_count() reports the whole
+    machine there), capped by OMP_NUM_THREADS when the harness sets it."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS", "")
+    if cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
+def cpu_baseline(frames_cfg, width, aspect, seconds_target=20.0):
+    """The CPU oracle (a port of the reference; the Rust binary cannot be built here) on a bounded sample of the
+    same workload: the same frames at full resolution and one reduced sample count for all of them, the
+    reference's own structure (pointer BVH, always-left-then-right walk, one pixel per task), on every host
+    thread this process may use."""
     sys.path.insert(0, str(ROOT / "tests"))
     import orc
-    threads = orc.DEFAULT_THREADS
+    threads = host_threads()
     h = rtamd.image_height(width, aspect)
-    rays_total, sec_total, spp_used = 0, 0.0, []
-    per_frame = seconds_target / len(frames_cfg)
-    for name in frames_cfg:
-        sc = orc.Scene(name, seed=1)
+    scenes = [orc.Scene(name, seed=1) for name in frames_cfg]
+    rays_total, sec_total = 0, 0.0
+    for sc in scenes:  # one sample per pixel of every frame: sizes the rest
         t0 = time.perf_counter()
         _, rays = sc.render(width, h, aspect, 1, depth=MAX_DEPTH, seed=1, mode=1, threads=threads)
-        dt = time.perf_counter() - t0
-        spp = int(max(1, min(64, per_frame / max(dt, 1e-3) - 1)))
-        if spp > 1:
-            t0 = time.perf_counter()
-            _, rays2 = sc.render(width, h, aspect, spp, depth=MAX_DEPTH, seed=1, mode=1, s0=1, threads=threads)
-            dt += time.perf_counter() - t0
-            rays += rays2
-            spp += 1
+        sec_total += time.perf_counter() - t0
         rays_total += rays
-        sec_total += dt
-        spp_used.append(spp)
+    spp = int(max(1, min(256, seconds_target / max(sec_total, 1e-3))))
+    if spp > 1:
+        for sc in scenes:
+            t0 = time.perf_counter()
+            _, rays = sc.render(width, h, aspect, spp - 1, depth=MAX_DEPTH, seed=1, mode=1, s0=1, threads=threads)
+            sec_total += time.perf_counter() - t0
+            rays_total += rays
+    for sc in scenes:
         sc.close()
     return {"value": rays_total / sec_total / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{'+'.join(frames_cfg)} at {width}x{h}, {'/'.join(map(str, spp_used))} spp each, depth {MAX_DEPTH}, "
+            "sample": f"{'+'.join(frames_cfg)} at {width}x{h}, {spp} spp each, depth {MAX_DEPTH}, "
                       f"oracle BVHNode path (oracle/rt_oracle.cpp), {sec_total:.1f} s"}
+
+
+def pmc_profile(workload, kernel):
+    """VALU counters of the dominant kernel from the newest committed PMC summary of this workload
+    (profiles/*_<workload>_<kernel>_pmc.json: valu_busy = share of SIMD cycles that issue a VALU instruction,
+    lane_use = active lanes per VALU instruction / 64).  None when no summary matches."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob(f"*_{workload}_{kernel}_pmc.json")):
+        try:
+            doc = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if "valu_busy" in doc and "lane_use" in doc:
+            best = {"valu_busy": doc["valu_busy"], "lane_use": doc["lane_use"], "source": f.name}
+    return best
+
+
+def kernel_rooflines(frames, stats, steps, workload, use_committed):
+    """Per-kernel HBM roofline figures of a set of timed steps.  stats: one list of per-frame rt_render stats per
+    step.  Every kernel is charged the bytes it has to move itself (never another formulation's); a scene that
+    fits one XCD's L2 is charged once per XCD and launch, a larger one per node fetch and primitive test, and where
+    that exceeds what HBM can deliver (upper tree levels served by L2 / Infinity Cache) the committed measured
+    traffic takes its place, so that no fraction above 1 is ever reported."""
+    sums = {k: sum(st[k] for s in stats for st in s) for k in ("trace_ms", "shade_ms", "bounce_ms", "tail_ms", "paths_ms")}
+    tr_bytes = sh_bytes = bo_bytes = pa_bytes = 0.0
+    for f, st_frame in zip(frames, zip(*stats)):
+        # per-ray node fetches / primitive tests of this frame: one instrumented pass at 1 spp (untimed)
+        f.ctx.profile(events=False, count_visits=True)
+        st = f.render(spp=1, exchange=False)  # rank 0 alone: no collective here
+        f.ctx.profile(events=True, count_visits=False)
+        nodes_pr = st["node_visits"] / max(st["rays"], 1)
+        prims_pr = st["prim_tests"] / max(st["rays"], 1)
+        f.nodes_per_ray, f.prims_per_ray = nodes_pr, prims_pr
+        # rays the tail kernel finished (the last few live paths of a batch) are timed apart from the per-bounce kernels
+        f_rays = sum(s["rays"] - s["tail_rays"] for s in st_frame)
+        f_paths = sum(s["paths"] for s in st_frame)
+        alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
+        mode = st_frame[0]["pipeline"]  # 0 split, 1 fused, 2 hybrid: camera rays fused, scattered rays split, 3 whole paths
+        if mode == 3:
+            # k_paths keeps a path in registers from its camera ray to its end: a pixel index in and a radiance out per
+            # path, the scene once per XCD and launch -- that is all it has to move
+            pa_bytes += f_paths * (4.0 + 16.0) + scene_bytes_per_launch(f.info) * sum(s["paths_launches"] for s in st_frame)
+            continue
+        fused_rays = f_rays if mode == 1 else (f_paths if mode == 2 else 0)
+        split_rays = f_rays - fused_rays
+        if fused_rays:
+            primary = f_paths / max(fused_rays, 1)
+            bo_bytes += fused_rays * bounce_bytes_per_ray(f.info, primary, alive, nodes_pr, prims_pr)
+            bo_bytes += scene_bytes_per_launch(f.info) * sum(s["bounce_kernel_launches"] for s in st_frame)
+        if split_rays:
+            tr_bytes += split_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
+            tr_bytes += scene_bytes_per_launch(f.info) * sum(s["trace_launches"] for s in st_frame)
+            sh_bytes += split_rays * shade_bytes_per_ray(alive)
+    launches = {k: sum(st[k] for s in stats for st in s) for k in ("trace_launches", "shade_launches", "bounce_kernel_launches", "paths_launches")}
+    cands = [("k_trace", sums["trace_ms"], tr_bytes, launches["trace_launches"]), ("k_shade", sums["shade_ms"], sh_bytes, launches["shade_launches"]),
+             ("k_bounce", sums["bounce_ms"], bo_bytes, launches["bounce_kernel_launches"]), ("k_paths", sums["paths_ms"], pa_bytes, launches["paths_launches"])]
+
+    def one(name, ms, nbytes, nl):
+        t = measured_traffic(workload, name) if use_committed else None
+        traffic = round(t[0] * 1.0 / max(t[2], 1), 1) if t else None  # per launch of the profiled run
+        per_launch = nbytes / max(nl, 1)
+        source = "algorithmic"
+        if ms > 0 and nbytes / (ms * 1e-3) / 1e9 > PEAK_HBM_GBPS and traffic:
+            # more than HBM can deliver: the upper tree levels came from L2 / the Infinity Cache.  Charge what was measured.
+            per_launch, source = traffic, "measured traffic (algorithmic node bytes exceed the HBM peak)"
+        ach = per_launch * nl / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        if ach > PEAK_HBM_GBPS:
+            # no measured traffic committed for this configuration: the figure is capped, not evidence
+            source = f"algorithmic, capped at the HBM peak (uncapped {ach:.0f} GB/s: upper tree levels are served by L2 / Infinity Cache)"
+            per_launch *= PEAK_HBM_GBPS / ach
+            ach = PEAK_HBM_GBPS
+        d = {"kernel": name, "achieved": round(ach, 2), "frac": round(ach / PEAK_HBM_GBPS, 5), "launches": int(nl),
+             "avg_launch_ms": round(ms / max(nl, 1), 5), "algorithmic_bytes_per_launch": round(per_launch, 1), "bytes_source": source,
+             "traffic": traffic, "traffic_source": t[1] if t else None}
+        pmc = pmc_profile(workload, name) if use_committed else None
+        if pmc:
+            d["valu"] = pmc
+        return d
+
+    ranked = sorted(cands, key=lambda k: -k[1])
+    top = one(*ranked[0])
+    # what limits the kernel: far below the HBM roofline with the VALUs busy means instruction issue, not memory
+    valu = top.get("valu")
+    bound = "valu" if (top["frac"] < 0.5 and (valu is None or valu["valu_busy"] >= 0.5)) else "hbm"
+    roof = {"bound": bound, "kernel": top["kernel"], "achieved": top["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": top["frac"], "traffic": top["traffic"], "traffic_source": top["traffic_source"], "launches": top["launches"],
+            "avg_launch_ms": top["avg_launch_ms"], "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
+            "bytes_source": top["bytes_source"],
+            # True: the scene fits an XCD's L2, so per-ray node/primitive fetches are cache hits and only the
+            # path-state stream (plus one scene read per XCD and launch) is charged to HBM
+            "scene_resident_in_l2": all(f.info["device_bytes"] <= L2_PER_XCD for f in frames),
+            "trace_ms_per_step": round(sums["trace_ms"] / steps, 3), "shade_ms_per_step": round(sums["shade_ms"] / steps, 3),
+            "bounce_ms_per_step": round(sums["bounce_ms"] / steps, 3), "tail_ms_per_step": round(sums["tail_ms"] / steps, 3),
+            "paths_ms_per_step": round(sums["paths_ms"] / steps, 3),
+            "nodes_per_ray": [round(f.nodes_per_ray, 2) for f in frames], "prims_per_ray": [round(f.prims_per_ray, 2) for f in frames]}
+    if valu:
+        roof["valu"] = valu
+    if bound == "valu":
+        roof["note"] = ("achieved/peak/frac are the kernel's algorithmic HBM bytes against the HBM peak; the kernel is bound by "
+                        "VALU instruction issue under divergence (valu: busy share of SIMD cycles, lanes active per instruction), "
+                        "not by memory")
+    # the other kernels that take a real share of the step, in the same terms
+    others = [one(*k) for k in ranked[1:] if k[1] > 0.15 * ranked[0][1] and k[3]]
+    if others:
+        roof["other_kernels"] = others
+    return roof
+
+
+def other_configs(device, n_synth):
+    """One frame each of BASELINE.json's configs[0..2] at their full sizes, outside the timed steps of the default
+    workload: ms per frame (second of two renders), Mrays/s, the kernel that took the most time and its HBM figures."""
+    rows = []
+    for wl in OTHER_CONFIGS:
+        frames_cfg, width, aspect, spp = WORKLOADS[wl]
+        frames = [Frame(n, width, aspect, spp, 0, 1, device, n_synth) for n in frames_cfg]
+        for f in frames:
+            f.ctx.profile(events=True)
+            f.render(exchange=False)  # allocations, kernel loading
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = [f.render(exchange=False) for f in frames]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        roof = kernel_rooflines(frames, [st], 1, wl, use_committed=False)
+        rays = sum(s["rays"] for s in st)
+        rows.append({"workload": wl, "frames": list(frames_cfg), "width": width, "height": frames[0].h, "spp": spp,
+                     "ms_per_frame": round(dt * 1e3 / len(frames), 3), "ms_per_step": round(dt * 1e3, 3),
+                     "mrays_per_s": round(rays / dt / 1e6, 1), "rays_per_step": rays,
+                     "dominant_kernel": roof["kernel"], "bound": roof["bound"], "hbm_frac": roof["frac"],
+                     "kernel_ms": {k[:-12]: roof[k] for k in roof if k.endswith("_ms_per_step") and roof[k] > 0}})
+        for f in frames:
+            f.ctx.close()
+        del frames
+        torch.cuda.empty_cache()
+    return rows
 
 
 def main():
@@ -190,12 +346,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2_textures", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (changes the workload; recorded in config)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--synth-n", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="CPU work the cpu_baseline sample is sized to")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="CPU work the cpu_baseline sample is sized to")
+    ap.add_argument("--no-others", action="store_true", help="skip the one-frame renders of the other BASELINE configs (config.others)")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event kernel timing (roofline becomes null)")
     ap.add_argument("--frames-at-once", type=int, default=-1, choices=[-1, 0, 1],
                     help="render the frames of a step concurrently, one HIP stream and host thread each (default: only "
@@ -294,97 +451,11 @@ def main():
         # dominant kernel and its roofline, from HIP events recorded around every launch of the timed steps
         roof = None
         if not args.no_profile:
-            trace_ms = sum(st["trace_ms"] for s in stats for st in s)
-            shade_ms = sum(st["shade_ms"] for s in stats for st in s)
-            bounce_ms = sum(st["bounce_ms"] for s in stats for st in s)
-            tail_ms = sum(st["tail_ms"] for s in stats for st in s)
-            paths_ms = sum(st["paths_ms"] for s in stats for st in s)
-            # per-ray node fetches / primitive tests of this workload: one instrumented pass at 1 spp (untimed)
-            tr_bytes = sh_bytes = bo_bytes = pa_bytes = pa_must = 0.0
-            for f, st_frame in zip(frames, zip(*stats)):
-                f.ctx.profile(events=False, count_visits=True)
-                st = f.render(spp=1, exchange=False)  # rank 0 alone: no collective here
-                f.ctx.profile(events=True, count_visits=False)
-                nodes_pr = st["node_visits"] / max(st["rays"], 1)
-                prims_pr = st["prim_tests"] / max(st["rays"], 1)
-                # rays the tail kernel finished (the last few live paths of a batch) are timed apart from the per-bounce kernels
-                f_rays = sum(s["rays"] - s["tail_rays"] for s in st_frame)
-                f_paths = sum(s["paths"] for s in st_frame)
-                alive = max(0.0, 1.0 - f_paths / max(f_rays, 1))  # every path ends exactly once
-                mode = st_frame[0]["pipeline"]  # 0 split, 1 fused, 2 hybrid: camera rays fused, scattered rays split, 3 whole paths
-                if mode == 3:
-                    # k_paths keeps a path's state in registers from bounce to bounce.  It is charged the per-ray figure of
-                    # the wavefront formulation all the same (state in + state out per bounce, as the metric's definition
-                    # has it), so that its rate compares with the per-bounce kernels'; what it really moves is `traffic`.
-                    primary = f_paths / max(f_rays, 1)
-                    pa_bytes += f_rays * bounce_bytes_per_ray(f.info, primary, alive, nodes_pr, prims_pr)
-                    pa_bytes += scene_bytes_per_launch(f.info) * sum(s["paths_launches"] for s in st_frame)
-                    # what k_paths itself has to move: a pixel index in and a radiance out per path, the scene once per XCD
-                    pa_must += f_paths * (4.0 + 16.0) + scene_bytes_per_launch(f.info) * sum(s["paths_launches"] for s in st_frame)
-                    continue
-                fused_rays = f_rays if mode == 1 else (f_paths if mode == 2 else 0)
-                split_rays = f_rays - fused_rays
-                if fused_rays:
-                    primary = f_paths / max(fused_rays, 1)
-                    bo_bytes += fused_rays * bounce_bytes_per_ray(f.info, primary, alive, nodes_pr, prims_pr)
-                    bo_bytes += scene_bytes_per_launch(f.info) * sum(s["bounce_kernel_launches"] for s in st_frame)
-                if split_rays:
-                    tr_bytes += split_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
-                    tr_bytes += scene_bytes_per_launch(f.info) * sum(s["trace_launches"] for s in st_frame)
-                    sh_bytes += split_rays * shade_bytes_per_ray(alive)
-            n_tr = sum(st["trace_launches"] for s in stats for st in s)
-            n_sh = sum(st["shade_launches"] for s in stats for st in s)
-            n_bo = sum(st["bounce_kernel_launches"] for s in stats for st in s)
-            n_pa = sum(st["paths_launches"] for s in stats for st in s)
-            cands = [("k_trace", trace_ms, tr_bytes, n_tr), ("k_shade", shade_ms, sh_bytes, n_sh),
-                     ("k_bounce", bounce_ms, bo_bytes, n_bo), ("k_paths", paths_ms, pa_bytes, n_pa)]
-            kernel, ms, nbytes, nl = max(cands, key=lambda k: k[1])
-            achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-
-            def traffic_per_launch(name, launches):
-                t = measured_traffic(args.workload, name) if not (args.spp or args.width) else None
-                return (round(t[0] * args.steps / max(launches, 1), 1), t[1]) if t else (None, None)
-
-            traffic = traffic_per_launch(kernel, nl)
-            roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 5),
-                    "traffic": traffic[0], "traffic_source": traffic[1],
-                    "launches": int(nl), "avg_launch_ms": round(ms / max(nl, 1), 5),
-                    "algorithmic_bytes_per_launch": round(nbytes / max(nl, 1), 1),
-                    # True: the scene fits an XCD's L2, so per-ray node/primitive fetches are cache hits and only the
-                    # path-state stream (plus one scene read per XCD and launch) is charged to HBM
-                    "scene_resident_in_l2": all(f.info["device_bytes"] <= L2_PER_XCD for f in frames),
-                    "trace_ms_per_step": round(trace_ms / args.steps, 3), "shade_ms_per_step": round(shade_ms / args.steps, 3),
-                    "bounce_ms_per_step": round(bounce_ms / args.steps, 3), "tail_ms_per_step": round(tail_ms / args.steps, 3),
-                    "paths_ms_per_step": round(paths_ms / args.steps, 3)}
-            # the other kernels that take a real share of the step, in the same terms (when two kernels take about the
-            # same time, which of them is "dominant" flips from run to run)
-            others = []
-            for k_name, k_ms, k_bytes, k_nl in cands:
-                if k_name != kernel and k_ms > 0.15 * ms and k_nl:
-                    k_ach = k_bytes / (k_ms * 1e-3) / 1e9
-                    k_tr = traffic_per_launch(k_name, k_nl)
-                    others.append({"kernel": k_name, "achieved": round(k_ach, 2), "frac": round(k_ach / PEAK_HBM_GBPS, 5),
-                                   "launches": int(k_nl), "avg_launch_ms": round(k_ms / k_nl, 5),
-                                   "algorithmic_bytes_per_launch": round(k_bytes / k_nl, 1), "traffic": k_tr[0],
-                                   "traffic_source": k_tr[1]})
-            if others:
-                roof["other_kernels"] = others
-            if kernel == "k_paths":
-                roof["note"] = ("k_paths follows whole paths in registers: the state bytes charged per bounce are those of the "
-                                "wavefront formulation and never reach HBM here (see traffic); own_bytes_* count only what this "
-                                "kernel must move -- it is bound by VALU issue, not by HBM")
-                roof["own_bytes_per_launch"] = round(pa_must / max(nl, 1), 1)
-                roof["own_bytes_frac"] = round(pa_must / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5)
+            roof = kernel_rooflines(frames, stats, args.steps, args.workload, use_committed=not (args.spp or args.width))
             if at_once:
                 # the frames share the GPU, so a kernel's HIP-event time includes the time it waited for the others'
                 # waves: the per-kernel figures of such a run are upper bounds of the time, lower bounds of the rate
                 roof["overlapped_streams"] = True
-            if achieved > PEAK_HBM_GBPS:
-                # only for scenes beyond L2 (64 B per node fetch charged to HBM): every ray walks the same upper
-                # levels of the tree, which L2 and the 256 MB MALL serve, so the algorithmic figure can exceed what HBM
-                # delivers; the measured traffic (profiles/) is the number to read there
-                roof["note"] = "algorithmic node bytes exceed the HBM peak: upper tree levels are served by L2/MALL"
 
         out = {
             "metric": "Mrays/s (paths x bounces)", "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s",
@@ -400,6 +471,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_cfg, width, aspect, args.cpu_baseline_seconds)
+            # vs_baseline stays null (the reference publishes no number); this is the ratio to the CPU port timed above
+            out["vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if world == 1 and args.workload == DEFAULT_WORKLOAD and not (args.no_others or args.no_profile or args.spp or args.width):
+            for f in frames:  # their queues (up to 72 GB) are not needed any more
+                f.ctx.close()
+            frames.clear()
+            torch.cuda.empty_cache()
+            out["config"]["others"] = other_configs(local_rank, args.synth_n)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
