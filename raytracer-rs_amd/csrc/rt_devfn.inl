@@ -397,7 +397,15 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     float a = dot3(d, d);
     float r1, r2;
     const uint32_t first = G.root_ref & 0x03FFFFFFu, cnt = ((G.root_ref >> 26) & 15u) + 1u;
-    if (cnt <= 8u) {
+    if (cnt == 1u) {
+        // one primitive (a sphere in every reference scene, main.rs:226-235, 281-284): the first query over the whole
+        // line takes the primitive's first candidate, the second query from r1 + 0.0001 on the first candidate at or
+        // beyond that -- the sphere's far root, nothing for a rect (shapes.rs:126-136, 655-656)
+        float c0, c1;
+        const uint32_t have = prim_roots(S, first, o, d, a, time, c0, c1);
+        if (!pick_root(have, c0, c1, -INF_F, INF_F, r1)) return;
+        if (!pick_root(have, c0, c1, r1 + 0.0001f, INF_F, r2)) return;
+    } else if (cnt <= 8u) {
         if (!boundary_pair(S, first, cnt, o, d, a, time, r1, r2)) return;
     } else {
         if (!list_closest(S, G.root_ref, o, d, a, time, -INF_F, INF_F, r1)) return;
