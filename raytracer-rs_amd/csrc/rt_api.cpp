@@ -99,6 +99,7 @@ struct rt_ctx {
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
     uint64_t n_owned = 0;
+    unsigned char* noalloc_scratch = nullptr;  // this device's copy of the static scratch array (rt_intersect_batch_noalloc)
     uint32_t* h_counts = nullptr;  // pinned: NSHARD queue counts, then the overflow flag
     unsigned long long* h_rays = nullptr;
 
@@ -416,6 +417,15 @@ int rt_ctx_create(int device, rt_ctx** out) {
     c->stream = c->own_stream;
     if (hipHostMalloc((void**)&c->h_counts, (rtk::NSHARD + 16) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_rays, 128, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return RT_ERR_HIP;
+    }
+    // device address of this GPU's copy of the static scratch array, looked up once per context with its device current
+    if (rtk::noalloc_scratch_address((void**)&c->noalloc_scratch) != hipSuccess || !c->noalloc_scratch) {
+        (void)hipGetLastError();
+        (void)hipHostFree(c->h_counts);
+        (void)hipHostFree(c->h_rays);
+        (void)hipStreamDestroy(c->own_stream);
         delete c;
         return RT_ERR_HIP;
     }
@@ -1096,6 +1106,59 @@ int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, 
         if (e2 != hipSuccess) return hip_fail(c, e2, "rt_intersect_batch sync");
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_counts + rtk::NSHARD, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
+    return RT_OK;
+}
+
+int rt_intersect_batch_noalloc(rt_ctx* c, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
+                               const float* dy, const float* dz, const float* time, float tmin, float tmax, uint32_t seed,
+                               int32_t* prim, int32_t* inst, float* t, float* normal, uint8_t* front, float* uv, float* point) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->committed) return fail(c, RT_ERR_NOT_COMMITTED, "rt_intersect_batch_noalloc before rt_scene_commit");
+    if (n == 0) return RT_OK;
+    if (n > rtk::NOALLOC_MAX_RAYS)
+        return fail(c, RT_ERR_INVALID, "rt_intersect_batch_noalloc: more than 65536 rays in one call (the limit of its static scratch); "
+                                       "split the batch or use rt_intersect_batch");
+    if (!ox || !oy || !oz || !dx || !dy || !dz || !time) return fail(c, RT_ERR_INVALID, "rt_intersect_batch_noalloc: null ray array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // every use of the scratch goes through the device address kept at rt_ctx_create, never through the array's name
+    unsigned char* const sc = c->noalloc_scratch;
+    uint32_t* const flag = (uint32_t*)sc;
+    const float* in[7] = {ox, oy, oz, dx, dy, dz, time};
+    const rtk::TraceCfg cfg{c->stack_entries, c->has_groups, false};
+    HIP_TRY(c, hipMemsetAsync(flag, 0, 4, c->stream));  // the array keeps the last call's contents
+    if (is_device_ptr(ox)) {
+        HIP_TRY(c, rtk::launch_intersect_batch(c->stream, cfg, c->scene, n, in, tmin, tmax, seed, prim, inst, t, normal, front, uv, point, flag));
+    } else {
+        // host arrays: staged through the scratch
+        float* din = (float*)(sc + rtk::NOALLOC_FLAG_BYTES);
+        unsigned char* o = sc + rtk::NOALLOC_FLAG_BYTES + rtk::NOALLOC_MAX_RAYS * 7 * 4;
+        const float* drays[7];
+        for (int k = 0; k < 7; k++) {
+            drays[k] = din + (size_t)k * rtk::NOALLOC_MAX_RAYS;
+            HIP_TRY(c, hipMemcpyAsync(din + (size_t)k * rtk::NOALLOC_MAX_RAYS, in[k], n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        }
+        const uint64_t M = rtk::NOALLOC_MAX_RAYS;
+        int32_t* d_prim = (int32_t*)o;
+        int32_t* d_inst = (int32_t*)(o + 4 * M);
+        float* d_t = (float*)(o + 8 * M);
+        float* d_normal = (float*)(o + 12 * M);
+        uint8_t* d_front = (uint8_t*)(o + 24 * M);
+        float* d_uv = (float*)(o + 28 * M);
+        float* d_point = (float*)(o + 36 * M);
+        HIP_TRY(c, rtk::launch_intersect_batch(c->stream, cfg, c->scene, n, drays, tmin, tmax, seed, prim ? d_prim : nullptr,
+                                               inst ? d_inst : nullptr, t ? d_t : nullptr, normal ? d_normal : nullptr,
+                                               front ? d_front : nullptr, uv ? d_uv : nullptr, point ? d_point : nullptr, flag));
+        if (prim) HIP_TRY(c, hipMemcpyAsync(prim, d_prim, 4 * n, hipMemcpyDeviceToHost, c->stream));
+        if (inst) HIP_TRY(c, hipMemcpyAsync(inst, d_inst, 4 * n, hipMemcpyDeviceToHost, c->stream));
+        if (t) HIP_TRY(c, hipMemcpyAsync(t, d_t, 4 * n, hipMemcpyDeviceToHost, c->stream));
+        if (normal) HIP_TRY(c, hipMemcpyAsync(normal, d_normal, 12 * n, hipMemcpyDeviceToHost, c->stream));
+        if (front) HIP_TRY(c, hipMemcpyAsync(front, d_front, n, hipMemcpyDeviceToHost, c->stream));
+        if (uv) HIP_TRY(c, hipMemcpyAsync(uv, d_uv, 8 * n, hipMemcpyDeviceToHost, c->stream));
+        if (point) HIP_TRY(c, hipMemcpyAsync(point, d_point, 12 * n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_counts + rtk::NSHARD, flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     return RT_OK;

@@ -81,6 +81,13 @@ hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& sc
 
 hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, uint32_t width, float* accum_rgb);
 hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, bool sqrt_transfer, uint8_t* out);
+// rt_intersect_batch_noalloc: at most this many rays per call; its per-GPU static scratch (flags + staging for
+// host callers: 28 bytes in and 48 bytes out per ray)
+constexpr uint64_t NOALLOC_MAX_RAYS = 65536;
+constexpr uint64_t NOALLOC_FLAG_BYTES = 256;
+constexpr uint64_t NOALLOC_SCRATCH_BYTES = NOALLOC_FLAG_BYTES + NOALLOC_MAX_RAYS * (7 * 4 + 48);
+// device address of the current device's copy of that scratch array
+hipError_t noalloc_scratch_address(void** out);
 hipError_t launch_intersect_batch(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, uint64_t n,
                                   const float* const rays[7], float tmin, float tmax, uint32_t seed, int32_t* prim,
                                   int32_t* inst, float* t, float* normal, uint8_t* front, float* uv, float* point,

@@ -620,6 +620,13 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
     }
 }
 
+// Scratch of the entry point that allocates nothing (rt_intersect_batch_noalloc): one array per GPU, held from the
+// moment the code object is loaded until the process ends.  Layout: 256 bytes of flags (word 0: traversal stack
+// overflow), then the staging area for callers that pass host arrays -- seven input arrays of NOALLOC_MAX_RAYS floats,
+// then the output arrays (prim, inst, t: 4 bytes per ray each; normal 12; front 1 padded to 4; uv 8; point 12).
+// In host code the name below is only a handle: the device address comes from hipGetSymbolAddress, once per device.
+static __device__ __align__(256) unsigned char scratch[rtk::NOALLOC_SCRATCH_BYTES];
+
 inline int grid_flat(unsigned long long n) {
     unsigned long long b = (n + rtk::BLOCK - 1) / rtk::BLOCK;
     if (b < 1) b = 1;
@@ -824,6 +831,11 @@ hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values
     else
         hipLaunchKernelGGL(k_resolve<false>, dim3(grid_flat(n_values)), dim3(BLOCK), 0, s, sum_rgb, (unsigned long long)n_values, inv, out);
     return hipGetLastError();
+}
+
+hipError_t noalloc_scratch_address(void** out) {
+    // with the device current whose copy of the array is wanted
+    return hipGetSymbolAddress(out, HIP_SYMBOL(scratch));
 }
 
 hipError_t launch_intersect_batch(hipStream_t s, const TraceCfg& cfg, const Scene& scene, uint64_t n, const float* const rays[7],

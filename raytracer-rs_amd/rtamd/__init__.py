@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_ctx_set_stream", "rt_ctx_set_max_paths",
     "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_reserve", "rt_ctx_set_builder", "rt_ctx_set_bvh_width", "rt_ctx_set_fuse_boxes", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
-    "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_render", "rt_profile_enable",
+    "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_intersect_batch_noalloc", "rt_render", "rt_profile_enable",
     "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_accum_write", "rt_accum_read", "rt_accum_write_tagged",
     "rt_accum_read_tagged", "rt_owned_pixels")
 
@@ -139,6 +139,7 @@ def core():
     L.rt_scene_commit.argtypes = [vp, f, f]
     L.rt_scene_get_info.argtypes = [vp, C.POINTER(rt_scene_info)]
     L.rt_intersect_batch.argtypes = [vp, u64] + [vp] * 7 + [f, f, u32] + [vp] * 7
+    L.rt_intersect_batch_noalloc.argtypes = [vp, u64] + [vp] * 7 + [f, f, u32] + [vp] * 7
     L.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_render_params), vp, C.POINTER(rt_render_stats)]
     L.rt_profile_enable.argtypes = [vp, C.c_int]
     L.rt_resolve_u8.argtypes = [vp, vp, u64, u32, vp]
@@ -478,8 +479,9 @@ class Context:
         return inf.as_dict()
 
     # ---- work ----------------------------------------------------------------------
-    def intersect(self, rays, tmin=0.005, tmax=float("inf"), seed=1, outputs=None):
-        """rays: (7, n) float32 numpy array or torch CUDA tensor.  Returns a dict of arrays of the same kind."""
+    def intersect(self, rays, tmin=0.005, tmax=float("inf"), seed=1, outputs=None, noalloc=False):
+        """rays: (7, n) float32 numpy array or torch CUDA tensor.  Returns a dict of arrays of the same kind.
+        noalloc: go through rt_intersect_batch_noalloc (at most 65536 rays, no device allocation inside the call)."""
         if not _is_torch(rays):
             rays = np.ascontiguousarray(rays, dtype=np.float32)
         _check_array(rays, "rays", "float32", (7, None), self.device)
@@ -496,7 +498,8 @@ class Context:
         if outputs is not None:
             out = {k: v for k, v in out.items() if k in outputs}
         g = lambda k: _ptr(out.get(k))
-        self._check(self.L.rt_intersect_batch(self.h, n, *[_ptr(rays[i]) for i in range(7)], tmin, tmax, seed,
+        fn = self.L.rt_intersect_batch_noalloc if noalloc else self.L.rt_intersect_batch
+        self._check(fn(self.h, n, *[_ptr(rays[i]) for i in range(7)], tmin, tmax, seed,
                                               g("prim"), g("inst"), g("t"), g("normal"), g("front"), g("uv"), g("point")))
         return out
 
