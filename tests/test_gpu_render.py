@@ -498,7 +498,7 @@ def test_c2_full_frame_properties(gpu_ctx):
     import torch
     w, aspect, spp = 1920, 16 / 9, 3
     h = rtamd.image_height(w, aspect)
-    for name in ("earth", "two_perlin_spheres"):
+    for name in ("earth", "two_spheres", "two_perlin_spheres"):
         gpu_ctx.load_scene(name, seed=1)
         cam = gpu_ctx.preset_camera(aspect)
         one = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
@@ -534,6 +534,28 @@ def test_c5_like_deep_bvh_properties(gpu_ctx):
     for r in range(4):
         gpu_ctx.render(w, h, cam, 1, seed=1, accum=four, rank=r, nranks=4)
     assert torch.equal(one, four)
+
+
+def test_c5_ten_million_spheres_properties():
+    """BASELINE configs[4] at its full 10M spheres (1920x1080, 1 spp): the scene builds on the device, takes the
+    four-child walk and the split pipeline, a 2-rank split reproduces the 1-rank frame bit for bit, every pixel is
+    finite and inside [0, 1], and rays >= paths."""
+    import torch
+    ctx = rtamd.Context(0)
+    info = ctx.load_scene("synth_spheres", seed=1, n_synth=10_000_000)
+    assert info["n_prims"] == 10_000_001 and info["builder"] == 1 and info["bvh_width"] == 4 and info["stack_entries"] <= 64
+    w, h = 1920, 1080
+    cam = ctx.preset_camera(16 / 9)
+    one = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    _, st = ctx.render(w, h, cam, 1, seed=1, accum=one)
+    assert st["pipeline"] == 0 and st["paths"] == w * h and st["rays"] >= st["paths"]
+    assert bool(torch.isfinite(one).all()) and float(one.min()) >= 0.0 and float(one.max()) <= 1.0
+    assert float(one.mean()) > 0.05  # not a black frame
+    two = torch.zeros_like(one)
+    for r in range(2):
+        ctx.render(w, h, cam, 1, seed=1, accum=two, rank=r, nranks=2)
+    assert torch.equal(one, two)
+    ctx.close()
 
 
 def test_cpp_example_renders_the_same_image_as_the_python_binding(tmp_path):
