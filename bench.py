@@ -65,7 +65,8 @@ def log(*a):
 class Frame:
     """One scene of the workload on this rank: context, camera, accumulation buffer, gather plan."""
 
-    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=32, gather_on_cpu=False, own_stream=False):
+    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=32, gather_on_cpu=False, own_stream=False,
+                 exchange="torch"):
         self.name, self.w, self.spp = name, width, spp
         self.h = rtamd.image_height(width, aspect)
         self.rank, self.world = rank, world
@@ -81,7 +82,48 @@ class Frame:
         self.tile = tile
         # the gloo rehearsal backend has no device collectives: stage the exchange through host memory there
         self.gather_dev = torch.device("cpu") if gather_on_cpu else self.accum.device
-        self.gather = TileGather(self.w, self.h, rank, world, self.gather_dev, tile) if world > 1 else None
+        self.gather = None
+        self.exchange_kind = "none"
+        if world > 1:
+            if exchange == "abi" and not gather_on_cpu and self._make_comm(rank, world, device):
+                # the exchange behind the C ABI: rt_gather_frame packs, runs ONE ncclAllGather on the context's own RCCL
+                # communicator and scatters -- what a host program without torch would call
+                self.exchange_kind = "abi"
+                self.frame = torch.empty_like(self.accum)
+            else:
+                self.exchange_kind = "torch"
+                self.gather = TileGather(self.w, self.h, rank, world, self.gather_dev, tile)
+
+    def _make_comm(self, rank, world, device):
+        """RCCL communicator of this frame's context, made through the C ABI; the 128-byte id travels over
+        torch.distributed.  Every step is agreed on by all ranks (a rank that cannot load RCCL must not leave the
+        others waiting in ncclCommInitRank): returns False on every rank if any rank failed."""
+        dev = f"cuda:{device}"
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+            return bool(t.item())
+
+        uid, ok = None, True
+        try:
+            uid = rtamd.comm_unique_id()  # (every rank: loads RCCL; only rank 0's bytes are used)
+        except rtamd.RtError as e:
+            log(f"rank {rank}: no RCCL for the C-ABI exchange ({e}); falling back to torch.distributed")
+            ok = False
+        if not all_ok(ok):
+            return False
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+        torch.distributed.broadcast(t, src=0)
+        try:
+            self.ctx.comm_create(bytes(t.cpu().tolist()), rank, world)
+        except rtamd.RtError as e:
+            log(f"rank {rank}: rt_comm_create failed ({e}); falling back to torch.distributed")
+            ok = False
+        if not all_ok(ok):
+            self.ctx.comm_destroy()
+            return False
+        return True
 
     def clear(self):
         self.accum.zero_()
@@ -92,8 +134,12 @@ class Frame:
         return st
 
     def exchange(self):
-        if self.gather is not None:
-            # framebuffer exchange: every rank owns disjoint tiles -> one all_gather of the packed tiles
+        # framebuffer exchange: every rank owns disjoint tiles -> one all_gather of the packed tiles
+        if self.exchange_kind == "abi":
+            if self.own_stream:
+                torch.cuda.current_stream().synchronize()
+            self.ctx.gather_frame(self.accum, tile_size=self.tile, out=self.frame)
+        elif self.gather is not None:
             self.frame = self.gather.gather(self.accum.to(self.gather_dev))
 
     def render(self, spp=None, exchange=True):
@@ -106,7 +152,7 @@ class Frame:
         return st
 
     def image(self):
-        return self.frame if self.gather is not None else self.accum
+        return self.frame if self.exchange_kind != "none" else self.accum
 
 
 L2_PER_XCD = 4 << 20  # a scene below this stays resident in every XCD's L2 for a whole launch
@@ -357,6 +403,9 @@ def main():
     ap.add_argument("--frames-at-once", type=int, default=-1, choices=[-1, 0, 1],
                     help="render the frames of a step concurrently, one HIP stream and host thread each (default: only "
                          "when the step is split over several ranks, where one rank's share of a frame no longer fills the GPU)")
+    ap.add_argument("--exchange", default="abi", choices=["abi", "torch"],
+                    help="frame exchange for N > 1: abi = rt_gather_frame (RCCL communicator made and driven through the C ABI), "
+                         "torch = torch.distributed all_gather_into_tensor; abi falls back to torch when RCCL cannot be loaded")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (exchange staged through host memory, ranks may share a GPU) "
                          "only rehearses the multi-rank path on a box with fewer GPUs than ranks")
@@ -388,7 +437,7 @@ def main():
     # the frames run one after the other, which also keeps the per-kernel HIP-event times free of overlap.
     at_once = len(frames_cfg) > 1 and (args.frames_at_once == 1 or (args.frames_at_once < 0 and world > 1))
     frames = [Frame(n, width, aspect, spp, rank, world, local_rank, args.synth_n, gather_on_cpu=args.backend == "gloo",
-                    own_stream=at_once)
+                    own_stream=at_once, exchange=args.exchange)
               for n in frames_cfg]
     pool = None
     if at_once:
@@ -464,7 +513,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "frames": list(frames_cfg), "width": width, "height": frames[0].h,
                        "spp": spp, "max_depth": MAX_DEPTH, "tile_split": f"32x32 tiles round-robin over {world} rank(s)",
-                       "frames_at_once": bool(at_once), "bvh_width": [f.info.get("bvh_width", 2) for f in frames],
+                       "frames_at_once": bool(at_once), "exchange": frames[0].exchange_kind, "bvh_width": [f.info.get("bvh_width", 2) for f in frames],
                        "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps,
                        "sec_per_frame": round(elapsed / args.steps / len(frames), 5)},
             "roofline": roof,

@@ -291,6 +291,36 @@ int rt_accum_read_tagged(const char* path, uint32_t* width, uint32_t* height, ui
 int rt_owned_pixels(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t rank, uint32_t nranks,
                     uint32_t* out, uint64_t cap, uint64_t* n);
 
+/* ---- frame exchange between ranks ---------------------------------------------------------
+ * The reference collects every pixel of the frame in one Vec (main.rs:463-482).  With the frame's tiles dealt over
+ * the ranks (rt_render: rank, nranks, tile_size) each rank's accumulation buffer holds only its own tiles; ONE
+ * collective per frame completes it everywhere: every rank packs its pixels (in rt_owned_pixels order, padded to the
+ * largest share), one ncclAllGather over the RCCL communicator of the context (each peer's block arrives over its
+ * own xGMI link), and a scatter back to frame order.  RCCL is not linked into the library: its entry points are
+ * taken from the RCCL the process has loaded (or librccl.so on the loader path), so a communicator the host program
+ * made with its own RCCL binding can be adopted (rt_comm_attach) as well as one made here (rt_comm_create).
+ *   rank 0:     rt_comm_unique_id(id);  ... send the 128 bytes to every rank by any means ...
+ *   every rank: rt_comm_create(ctx, id, rank, nranks);          (collective: all ranks must call it)
+ *   per frame:  rt_render(..., rank, nranks, ...);  rt_gather_frame(ctx, w, h, tile_size, accum, frame);
+ * rt_gather_frame with a single rank needs no communicator and no RCCL.  accum_rgb, frame_rgb: height x width x 3
+ * floats, host or device, may not overlap. */
+int rt_comm_unique_id(uint8_t out[128]);
+int rt_comm_create(rt_ctx* ctx, const uint8_t unique_id[128], uint32_t rank, uint32_t nranks);
+/* Adopts an ncclComm_t the caller made (not destroyed with the context); NULL with nranks == 1 detaches. */
+int rt_comm_attach(rt_ctx* ctx, void* nccl_comm, uint32_t rank, uint32_t nranks);
+int rt_comm_destroy(rt_ctx* ctx);
+int rt_gather_frame(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t tile_size, const float* accum_rgb,
+                    float* frame_rgb);
+/* The two device steps on their own (device pointers; for callers that run the collective themselves, and for
+ * tests with several virtual ranks on one GPU).  A rank's block holds rt_frame_block_pixels(...) pixels (3 floats
+ * each): the largest share of any rank; rt_pack_owned writes this rank's pixels to the front of `packed`;
+ * rt_scatter_gathered reads nranks such blocks, rank r's at gathered + 3 * r * block_pixels. */
+int rt_frame_block_pixels(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint64_t* out);
+int rt_pack_owned(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t rank, uint32_t nranks,
+                  const float* accum_rgb, float* packed);
+int rt_scatter_gathered(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks,
+                        const float* gathered, float* frame_rgb);
+
 #ifdef __cplusplus
 }
 #endif

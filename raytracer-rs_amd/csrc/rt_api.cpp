@@ -1,6 +1,7 @@
 // C ABI of the MI355X render path: context, scene upload, BVH commit, ray-batch and render drivers.
 // Compiled with hipcc; there is no CPU fallback: every work call needs a GPU and fails with
 // RT_ERR_NO_DEVICE / RT_ERR_HIP otherwise.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -99,6 +100,13 @@ struct rt_ctx {
     DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
     uint64_t n_owned = 0;
+    // frame exchange between ranks (rt_comm_*, rt_gather_frame)
+    void* comm = nullptr;       // ncclComm_t of the RCCL library this process has loaded
+    bool comm_owned = false;    // made by rt_comm_create (destroyed with the context) or adopted from the caller
+    uint32_t comm_rank = 0, comm_nranks = 1;
+    DevBuf d_tile_off, d_packed, d_gathered, d_xin, d_xout;
+    uint64_t deal_key[4] = {0, 0, 0, 0};
+    uint64_t deal_block_pixels = 0;  // pixels of the largest rank's share (every rank's block is padded to it)
     unsigned char* noalloc_scratch = nullptr;  // this device's copy of the static scratch array (rt_intersect_batch_noalloc)
     uint32_t* h_counts = nullptr;  // pinned: NSHARD queue counts, then the overflow flag
     unsigned long long* h_rays = nullptr;
@@ -452,6 +460,9 @@ void rt_ctx_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)rt_comm_destroy(c);
+    DevBuf* xbufs[] = {&c->d_tile_off, &c->d_packed, &c->d_gathered, &c->d_xin, &c->d_xout};
+    for (DevBuf* b : xbufs) b->release();
     DevBuf* bufs[] = {&c->d_prims, &c->d_moving, &c->d_nodes, &c->d_wide, &c->d_groups, &c->d_mats, &c->d_texs, &c->d_perlin,
                       &c->d_images, &c->d_media, &c->d_hits, &c->d_radiance, &c->d_counts, &c->d_rays, &c->d_overflow, &c->d_pixels,
                       &c->d_accum};
@@ -1182,6 +1193,212 @@ int rt_owned_pixels(uint32_t width, uint32_t height, uint32_t tile_size, uint32_
             }
     }
     *n_out = n;
+    return RT_OK;
+}
+
+// ---- frame exchange ---------------------------------------------------------------------------------------------
+// RCCL is not linked: its entry points are looked up in the process at first use (the library the caller already
+// loaded, if any -- a communicator must be used with the library that made it -- else librccl.so from the loader path).
+namespace {
+struct UniqueId {
+    char internal[128];  // ncclUniqueId: NCCL_UNIQUE_ID_BYTES, passed by value
+};
+struct Rccl {
+    bool tried = false, ok = false;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+bool rccl_load() {
+    if (g_rccl.tried) return g_rccl.ok;
+    g_rccl.tried = true;
+    void* h = nullptr;
+    if (dlsym(RTLD_DEFAULT, "ncclAllGather")) h = RTLD_DEFAULT;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    for (int k = 0; !h && k < 3; k++) h = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, UniqueId, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather;
+    return g_rccl.ok;
+}
+int rccl_fail(rt_ctx* c, int code, const char* what) {
+    return fail(c, RT_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "RCCL error"));
+}
+constexpr int NCCL_FLOAT32 = 7;  // ncclFloat32 of rccl.h
+
+// Tile offsets of the deal (width, height, tile, nranks) on the device, cached per context.
+int prepare_deal(rt_ctx* c, uint32_t width, uint32_t height, uint32_t ts, uint32_t nranks, rtk::TileDeal& d) {
+    const uint32_t tx = (width + ts - 1) / ts, ty = (height + ts - 1) / ts;
+    const uint64_t key[4] = {width, height, ts, nranks};
+    if (memcmp(key, c->deal_key, sizeof(key)) != 0 || !c->d_tile_off.p) {
+        std::vector<uint32_t> off((size_t)tx * ty);
+        std::vector<uint64_t> fill(nranks, 0);
+        for (uint64_t tile = 0; tile < (uint64_t)tx * ty; tile++) {
+            const uint32_t x0 = (uint32_t)(tile % tx) * ts, y0 = (uint32_t)(tile / tx) * ts;
+            const uint32_t tw = std::min(width, x0 + ts) - x0, th = std::min(height, y0 + ts) - y0;
+            uint64_t& f = fill[tile % nranks];
+            off[tile] = (uint32_t)f;
+            f += (uint64_t)tw * th;
+        }
+        int rc = upload(c, c->d_tile_off, off.data(), off.size() * sizeof(uint32_t));
+        if (rc) return rc;
+        c->deal_block_pixels = *std::max_element(fill.begin(), fill.end());
+        memcpy(c->deal_key, key, sizeof(key));
+    }
+    d = rtk::TileDeal{width, height, ts, tx, nranks, (const uint32_t*)c->d_tile_off.p};
+    return RT_OK;
+}
+int check_frame_args(rt_ctx* c, uint32_t width, uint32_t height, uint32_t nranks, uint32_t rank, const void* a, const void* b) {
+    if (!c) return RT_ERR_INVALID;
+    if (!a || !b) return fail(c, RT_ERR_INVALID, "frame exchange: null buffer");
+    if (width < 1 || height < 1 || width > 65535 || height > 65535 || (uint64_t)width * height > (1ull << 31))
+        return fail(c, RT_ERR_INVALID, "frame exchange: image size out of range");
+    if (nranks < 1 || rank >= nranks) return fail(c, RT_ERR_INVALID, "frame exchange: rank >= nranks");
+    return RT_OK;
+}
+}  // namespace
+
+int rt_frame_block_pixels(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, uint64_t* out) {
+    if (!out || !width || !height) return RT_ERR_INVALID;
+    if (!nranks) nranks = 1;
+    uint64_t most = 0;
+    for (uint32_t r = 0; r < nranks; r++) {
+        uint64_t n = 0;
+        int rc = rt_owned_pixels(width, height, tile_size, r, nranks, nullptr, 0, &n);
+        if (rc) return rc;
+        most = std::max(most, n);
+    }
+    *out = most;
+    return RT_OK;
+}
+
+int rt_pack_owned(rt_ctx* c, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t rank, uint32_t nranks, const float* accum_rgb,
+                  float* packed) {
+    if (!nranks) nranks = 1;
+    int rc = check_frame_args(c, width, height, nranks, rank, accum_rgb, packed);
+    if (rc) return rc;
+    if (!is_device_ptr(accum_rgb) || !is_device_ptr(packed)) return fail(c, RT_ERR_INVALID, "rt_pack_owned: device pointers expected");
+    HIP_TRY(c, hipSetDevice(c->device));
+    rtk::TileDeal d;
+    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : 32, nranks, d))) return rc;
+    HIP_TRY(c, rtk::launch_pack_owned(c->stream, d, rank, accum_rgb, packed));
+    return RT_OK;
+}
+
+int rt_scatter_gathered(rt_ctx* c, uint32_t width, uint32_t height, uint32_t tile_size, uint32_t nranks, const float* gathered,
+                        float* frame_rgb) {
+    if (!nranks) nranks = 1;
+    int rc = check_frame_args(c, width, height, nranks, 0, gathered, frame_rgb);
+    if (rc) return rc;
+    if (!is_device_ptr(gathered) || !is_device_ptr(frame_rgb)) return fail(c, RT_ERR_INVALID, "rt_scatter_gathered: device pointers expected");
+    HIP_TRY(c, hipSetDevice(c->device));
+    rtk::TileDeal d;
+    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : 32, nranks, d))) return rc;
+    HIP_TRY(c, rtk::launch_scatter_gathered(c->stream, d, gathered, c->deal_block_pixels, frame_rgb));
+    return RT_OK;
+}
+
+int rt_comm_unique_id(uint8_t out[128]) {
+    if (!out) return RT_ERR_INVALID;
+    if (!rccl_load()) return RT_ERR_UNSUPPORTED;
+    UniqueId id;
+    memset(&id, 0, sizeof(id));
+    if (g_rccl.GetUniqueId(&id) != 0) return RT_ERR_HIP;
+    memcpy(out, id.internal, 128);
+    return RT_OK;
+}
+
+int rt_comm_create(rt_ctx* c, const uint8_t unique_id[128], uint32_t rank, uint32_t nranks) {
+    if (!c || !unique_id) return RT_ERR_INVALID;
+    if (nranks < 1 || rank >= nranks) return fail(c, RT_ERR_INVALID, "rt_comm_create: rank >= nranks");
+    if (!rccl_load()) return fail(c, RT_ERR_UNSUPPORTED, "rt_comm_create: no RCCL library (librccl.so) in this process or on the loader path");
+    HIP_TRY(c, hipSetDevice(c->device));
+    (void)rt_comm_destroy(c);
+    UniqueId id;
+    memcpy(id.internal, unique_id, 128);
+    void* comm = nullptr;
+    const int r = g_rccl.CommInitRank(&comm, (int)nranks, id, (int)rank);
+    if (r != 0 || !comm) return rccl_fail(c, r, "ncclCommInitRank");
+    c->comm = comm;
+    c->comm_owned = true;
+    c->comm_rank = rank;
+    c->comm_nranks = nranks;
+    return RT_OK;
+}
+
+int rt_comm_attach(rt_ctx* c, void* nccl_comm, uint32_t rank, uint32_t nranks) {
+    if (!c) return RT_ERR_INVALID;
+    if (nranks < 1 || rank >= nranks) return fail(c, RT_ERR_INVALID, "rt_comm_attach: rank >= nranks");
+    if (nccl_comm && !rccl_load()) return fail(c, RT_ERR_UNSUPPORTED, "rt_comm_attach: no RCCL library in this process");
+    if (!nccl_comm && nranks != 1) return fail(c, RT_ERR_INVALID, "rt_comm_attach: a null communicator only stands for a single rank");
+    (void)rt_comm_destroy(c);
+    c->comm = nccl_comm;
+    c->comm_owned = false;
+    c->comm_rank = rank;
+    c->comm_nranks = nranks;
+    return RT_OK;
+}
+
+int rt_comm_destroy(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    if (c->comm && c->comm_owned && g_rccl.ok) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)g_rccl.CommDestroy(c->comm);
+    }
+    c->comm = nullptr;
+    c->comm_owned = false;
+    c->comm_rank = 0;
+    c->comm_nranks = 1;
+    return RT_OK;
+}
+
+int rt_gather_frame(rt_ctx* c, uint32_t width, uint32_t height, uint32_t tile_size, const float* accum_rgb, float* frame_rgb) {
+    if (!c) return RT_ERR_INVALID;
+    const uint32_t nranks = c->comm_nranks, rank = c->comm_rank;
+    int rc = check_frame_args(c, width, height, nranks, rank, accum_rgb, frame_rgb);
+    if (rc) return rc;
+    if (nranks > 1 && !c->comm) return fail(c, RT_ERR_INVALID, "rt_gather_frame: no communicator (rt_comm_create / rt_comm_attach)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t frame_bytes = (size_t)width * height * 3 * sizeof(float);
+    const bool in_dev = is_device_ptr(accum_rgb), out_dev = is_device_ptr(frame_rgb);
+    const float* d_in = accum_rgb;
+    float* d_out = frame_rgb;
+    if (!in_dev) {
+        if ((rc = ensure(c, c->d_xin, frame_bytes))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_xin.p, accum_rgb, frame_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = (const float*)c->d_xin.p;
+    }
+    if (!out_dev) {
+        if ((rc = ensure(c, c->d_xout, frame_bytes))) return rc;
+        d_out = (float*)c->d_xout.p;
+    }
+    rtk::TileDeal d;
+    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : 32, nranks, d))) return rc;
+    const uint64_t block = c->deal_block_pixels;  // every rank's share, padded to the largest
+    if ((rc = ensure(c, c->d_gathered, (size_t)nranks * block * 3 * sizeof(float)))) return rc;
+    float* gathered = (float*)c->d_gathered.p;
+    if (nranks == 1) {
+        // one rank owns every tile: its packed block is the gathered buffer
+        HIP_TRY(c, rtk::launch_pack_owned(c->stream, d, 0, d_in, gathered));
+    } else {
+        if ((rc = ensure(c, c->d_packed, (size_t)block * 3 * sizeof(float)))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_packed.p, 0, (size_t)block * 3 * sizeof(float), c->stream));  // the padding of a smaller share
+        HIP_TRY(c, rtk::launch_pack_owned(c->stream, d, rank, d_in, (float*)c->d_packed.p));
+        // ONE collective per frame: every rank's block goes to every rank, each over its own xGMI link
+        const int r = g_rccl.AllGather(c->d_packed.p, gathered, (size_t)block * 3, NCCL_FLOAT32, c->comm, c->stream);
+        if (r != 0) return rccl_fail(c, r, "ncclAllGather");
+    }
+    HIP_TRY(c, rtk::launch_scatter_gathered(c->stream, d, gathered, block, d_out));
+    if (!out_dev) HIP_TRY(c, hipMemcpyAsync(frame_rgb, d_out, frame_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

@@ -81,6 +81,14 @@ hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& sc
 
 hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, uint32_t width, float* accum_rgb);
 hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values, uint32_t spp, bool sqrt_transfer, uint8_t* out);
+// ---- frame exchange: pixels of a rank's tiles <-> its block of the gathered buffer ---------------------------------
+struct TileDeal {
+    uint32_t width, height, tile, tiles_x, nranks;
+    const uint32_t* tile_off;  // per tile: position of its first pixel in its owner's block (device)
+};
+hipError_t launch_pack_owned(hipStream_t s, const TileDeal& d, uint32_t rank, const float* accum_rgb, float* packed);
+hipError_t launch_scatter_gathered(hipStream_t s, const TileDeal& d, const float* gathered, uint64_t block_pixels, float* frame_rgb);
+
 // rt_intersect_batch_noalloc: at most this many rays per call; its per-GPU static scratch (flags + staging for
 // host callers: 28 bytes in and 48 bytes out per ray)
 constexpr uint64_t NOALLOC_MAX_RAYS = 65536;

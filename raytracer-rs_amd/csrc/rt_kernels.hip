@@ -547,6 +547,43 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restr
     }
 }
 
+// Frame exchange (main.rs:463-482 collects every pixel in one Vec; with the frame's tiles dealt over ranks, each rank
+// holds only its own).  Pixels of a rank's tiles are packed in the order rt_owned_pixels lists them: tiles by index,
+// rows inside a tile, so tile_off[tile] + (y - y0) * tile_width + (x - x0) is a pixel's place in its owner's block.
+DEV uint32_t exchange_slot(const rtk::TileDeal& d, uint32_t p, uint32_t& owner) {
+    const uint32_t y = p / d.width, x = p - y * d.width;
+    const uint32_t tyi = y / d.tile, txi = x / d.tile;
+    const uint32_t tile = tyi * d.tiles_x + txi;
+    const uint32_t x0 = txi * d.tile, y0 = tyi * d.tile;
+    const uint32_t tw = (x0 + d.tile <= d.width ? d.tile : d.width - x0);
+    owner = tile % d.nranks;
+    return d.tile_off[tile] + (y - y0) * tw + (x - x0);
+}
+__global__ __launch_bounds__(rtk::BLOCK) void k_pack_owned(rtk::TileDeal d, uint32_t rank, const float* __restrict__ accum_rgb,
+                                                            float* __restrict__ packed) {
+    const uint32_t n = d.width * d.height;
+    for (uint32_t p = blockIdx.x * rtk::BLOCK + threadIdx.x; p < n; p += gridDim.x * rtk::BLOCK) {
+        uint32_t owner;
+        const uint32_t slot = exchange_slot(d, p, owner);
+        if (owner != rank) continue;
+        packed[3ull * slot] = accum_rgb[3ull * p];
+        packed[3ull * slot + 1] = accum_rgb[3ull * p + 1];
+        packed[3ull * slot + 2] = accum_rgb[3ull * p + 2];
+    }
+}
+__global__ __launch_bounds__(rtk::BLOCK) void k_scatter_gathered(rtk::TileDeal d, const float* __restrict__ gathered,
+                                                                  unsigned long long block_pixels, float* __restrict__ frame_rgb) {
+    const uint32_t n = d.width * d.height;
+    for (uint32_t p = blockIdx.x * rtk::BLOCK + threadIdx.x; p < n; p += gridDim.x * rtk::BLOCK) {
+        uint32_t owner;
+        const uint32_t slot = exchange_slot(d, p, owner);
+        const float* src = gathered + 3ull * (owner * block_pixels + slot);
+        frame_rgb[3ull * p] = src[0];
+        frame_rgb[3ull * p + 1] = src[1];
+        frame_rgb[3ull * p + 2] = src[2];
+    }
+}
+
 template <bool SQRT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_resolve(const float* __restrict__ sum_rgb, unsigned long long n, float inv,
                                                          uint8_t* __restrict__ out) {
@@ -830,6 +867,16 @@ hipError_t launch_resolve(hipStream_t s, const float* sum_rgb, uint64_t n_values
         hipLaunchKernelGGL(k_resolve<true>, dim3(grid_flat(n_values)), dim3(BLOCK), 0, s, sum_rgb, (unsigned long long)n_values, inv, out);
     else
         hipLaunchKernelGGL(k_resolve<false>, dim3(grid_flat(n_values)), dim3(BLOCK), 0, s, sum_rgb, (unsigned long long)n_values, inv, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_owned(hipStream_t s, const TileDeal& d, uint32_t rank, const float* accum_rgb, float* packed) {
+    hipLaunchKernelGGL(k_pack_owned, dim3(grid_flat((unsigned long long)d.width * d.height)), dim3(BLOCK), 0, s, d, rank, accum_rgb, packed);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_gathered(hipStream_t s, const TileDeal& d, const float* gathered, uint64_t block_pixels, float* frame_rgb) {
+    hipLaunchKernelGGL(k_scatter_gathered, dim3(grid_flat((unsigned long long)d.width * d.height)), dim3(BLOCK), 0, s, d, gathered,
+                       (unsigned long long)block_pixels, frame_rgb);
     return hipGetLastError();
 }
 

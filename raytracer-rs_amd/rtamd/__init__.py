@@ -33,7 +33,8 @@ ABI_SYMBOLS = (
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_intersect_batch_noalloc", "rt_render", "rt_profile_enable",
     "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_accum_write", "rt_accum_read", "rt_accum_write_tagged",
-    "rt_accum_read_tagged", "rt_owned_pixels")
+    "rt_accum_read_tagged", "rt_owned_pixels", "rt_comm_unique_id", "rt_comm_create", "rt_comm_attach", "rt_comm_destroy",
+    "rt_gather_frame", "rt_frame_block_pixels", "rt_pack_owned", "rt_scatter_gathered")
 
 
 class RtError(RuntimeError):
@@ -150,6 +151,14 @@ def core():
     L.rt_accum_write_tagged.argtypes = [C.c_char_p, u32, u32, u32, u32, u64, vp]
     L.rt_accum_read_tagged.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), vp, u64]
     L.rt_owned_pixels.argtypes = [u32, u32, u32, u32, u32, vp, u64, C.POINTER(u64)]
+    L.rt_comm_unique_id.argtypes = [vp]
+    L.rt_comm_create.argtypes = [vp, vp, u32, u32]
+    L.rt_comm_attach.argtypes = [vp, vp, u32, u32]
+    L.rt_comm_destroy.argtypes = [vp]
+    L.rt_gather_frame.argtypes = [vp, u32, u32, u32, vp, vp]
+    L.rt_frame_block_pixels.argtypes = [u32, u32, u32, u32, C.POINTER(u64)]
+    L.rt_pack_owned.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp]
+    L.rt_scatter_gathered.argtypes = [vp, u32, u32, u32, u32, vp, vp]
     for s in ABI_SYMBOLS:
         fn = getattr(L, s)
         if s not in ("rt_ctx_destroy", "rt_last_error"):
@@ -243,6 +252,24 @@ def owned_pixels(width, height, tile_size=32, rank=0, nranks=1):
     out = np.empty(n.value, dtype=np.uint32)
     core().rt_owned_pixels(width, height, tile_size, rank, nranks, _ptr(out), n.value, C.byref(n))
     return out
+
+
+def frame_block_pixels(width, height, tile_size=32, nranks=1):
+    """Pixels of the largest share of any rank: the size of one rank's block in the frame exchange."""
+    n = C.c_uint64(0)
+    rc = core().rt_frame_block_pixels(width, height, tile_size, nranks, C.byref(n))
+    if rc:
+        raise RtError(rc, "rt_frame_block_pixels")
+    return n.value
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes it, every rank passes the same bytes to Context.comm_create)."""
+    buf = (C.c_uint8 * 128)()
+    rc = core().rt_comm_unique_id(buf)
+    if rc:
+        raise RtError(rc, "rt_comm_unique_id (is an RCCL library available?)")
+    return bytes(buf)
 
 
 def flatten_counts(name, seed=1, n_synth=0, earthmap=None):
@@ -521,6 +548,37 @@ class Context:
         st = rt_render_stats()
         self._check(self.L.rt_render(self.h, C.byref(cam), C.byref(p), _ptr(accum), C.byref(st)))
         return accum, st.as_dict()
+
+    # ---- frame exchange ------------------------------------------------------------
+    def comm_create(self, unique_id, rank, nranks):
+        """Collective: every rank calls it with the same 128 bytes (comm_unique_id() of rank 0)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.L.rt_comm_create(self.h, buf, rank, nranks))
+
+    def comm_destroy(self):
+        self._check(self.L.rt_comm_destroy(self.h))
+
+    def gather_frame(self, accum, tile_size=32, out=None):
+        """One collective per frame: (h, w, 3) with this rank's tiles filled in -> the complete frame on every rank."""
+        _check_array(accum, "accum", "float32", (None, None, 3), self.device)
+        h, w = int(accum.shape[0]), int(accum.shape[1])
+        if out is None:
+            if _is_torch(accum):
+                import torch
+                out = torch.empty_like(accum)
+            else:
+                out = np.empty_like(accum)
+        _check_array(out, "out", "float32", (h, w, 3), self.device)
+        self._check(self.L.rt_gather_frame(self.h, w, h, tile_size, _ptr(accum), _ptr(out)))
+        return out
+
+    def pack_owned(self, accum, packed, tile_size, rank, nranks):
+        h, w = int(accum.shape[0]), int(accum.shape[1])
+        self._check(self.L.rt_pack_owned(self.h, w, h, tile_size, rank, nranks, _ptr(accum), _ptr(packed)))
+
+    def scatter_gathered(self, gathered, frame, tile_size, nranks):
+        h, w = int(frame.shape[0]), int(frame.shape[1])
+        self._check(self.L.rt_scatter_gathered(self.h, w, h, tile_size, nranks, _ptr(gathered), _ptr(frame)))
 
     def resolve_u8(self, accum, spp, transfer=0):
         """transfer 0: linear (main.rs:307-313); 1: square root first (the commented-out write_color, main.rs:35-42)."""
