@@ -1,0 +1,55 @@
+// Host-logic check (no GPU) of what the C++ mirror of the reference's scene API accepts: the reference lets
+// TransformedObject<T> and ConstantMedium<T> wrap any Hittable (shapes.rs:26-41, 624-646); the device takes ONE level
+// of transform and media at the top level.  Anything deeper must be refused with a message that says so -- never
+// flattened into something else.
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../raytracer-rs_amd/host/rt_scene.hpp"
+
+using namespace rt;
+
+template <class F>
+static bool refuses(const char* what, F build, const char* needle) {
+    FlatScene fs;
+    try {
+        build(fs);
+    } catch (const std::exception& e) {
+        if (std::strstr(e.what(), needle)) return true;
+        std::printf("FAIL %s: message '%s' lacks '%s'\n", what, e.what(), needle);
+        return false;
+    }
+    std::printf("FAIL %s: accepted\n", what);
+    return false;
+}
+
+int main() {
+    const Mat4 shift = Mat4::from_translation(Vec3(1.0f, 2.0f, 3.0f));
+    const Mat4 turn = Mat4::from_rotation_y(0.3f);
+    bool ok = true;
+    {  // one level: accepted, one instance group, ids 0..5 for the box sides
+        FlatScene fs;
+        auto inst = TransformedObject<Box2>::new_(Box2::new_(1.0f, 2.0f, 3.0f, LambertianMat::from_color(Vec3A(0.5f, 0.5f, 0.5f))), shift);
+        inst.flatten(fs, 0);
+        if (fs.groups.size() != 1 || fs.rect_id.size() != 6 || fs.rect_group[0] != 1) {
+            std::printf("FAIL one level\n");
+            ok = false;
+        }
+    }
+    ok &= refuses("transform inside transform", [&](FlatScene& fs) {
+        auto inner = TransformedObject<Sphere>::new_(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), turn);
+        TransformedObject<TransformedObject<Sphere>>::new_(inner, shift).flatten(fs, 0);
+    }, "nested");
+    ok &= refuses("medium inside transform", [&](FlatScene& fs) {
+        auto fog = ConstantMedium<Sphere>::from_color(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), 0.1f, Vec3A(1, 1, 1));
+        TransformedObject<ConstantMedium<Sphere>>::new_(fog, shift).flatten(fs, 0);
+    }, "nested");
+    ok &= refuses("transform inside the transform a medium wraps", [&](FlatScene& fs) {
+        auto inner = TransformedObject<Sphere>::new_(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), turn);
+        auto outer = TransformedObject<TransformedObject<Sphere>>::new_(inner, shift);
+        ConstantMedium<TransformedObject<TransformedObject<Sphere>>>::from_color(outer, 0.1f, Vec3A(1, 1, 1)).flatten(fs, 0);
+    }, "nested");
+    std::printf(ok ? "OK\n" : "FAILED\n");
+    return ok ? 0 : 1;
+}

@@ -202,6 +202,16 @@ def test_error_paths(gpu_ctx):
     ctx.set_scene(spheres=moving, materials=mats, textures=texs, shutter=(0.0, 2.0))
     ctx.render(8, 8, late, 1)
     ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0]), materials=mats, textures=texs)
+    # a medium boundary of more than 16 primitives (ConstantMedium<T> takes any T, shapes.rs:624-646; the device
+    # evaluates the boundary as one primitive list): refused at commit with the limit in the message
+    many = dict(c0r=[[float(i), 0, 0, 0.4] for i in range(17)], mat=[0] * 17, id=list(range(17)), group=[1] * 17)
+    fog = rtamd.rt_group(kind=2, has_xform=0, neg_inv_density=-1.0, mat=0)
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.set_scene(spheres=many, groups=[fog], materials=mats, textures=texs)
+    assert e.value.code == -3 and "16" in str(e.value)
+    with pytest.raises(rtamd.RtError):
+        ctx.intersect(one_ray((0, 0, 0), (0, 0, 1)))  # the failed commit left no scene behind
+    ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0]), materials=mats, textures=texs)
     img, st = ctx.render(8, 8, cam, 2, depth=253)
     assert st["rays"] >= 128 and np.isfinite(img).all()
     ctx.reserve(1 << 20)  # queues allocated ahead of time: same image
