@@ -670,10 +670,17 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     for (uint32_t i = 0; i < c->rect.n; i++) members[c->rect.group[i]].push_back({false, i});
     auto id_of = [&](const PrimSrc& s) { return s.sphere ? c->sph.id[s.idx] : c->rect.id[s.idx]; };
     for (auto& v : members) std::sort(v.begin(), v.end(), [&](const PrimSrc& a, const PrimSrc& b) { return id_of(a) < id_of(b); });
-    // A Box2 (six rects, shapes.rs:456-466) becomes one record and one leaf: the tree over the world loses two to
-    // three levels where boxes dominate (final_scene: 2400 rects -> 400 boxes) and the six tests share three
-    // reciprocals.  Medium boundaries keep their rects (the boundary queries want the separate roots).
-    if (c->fuse_boxes)
+    // Scenes of a few dozen primitives are traced without the tree (see rtd::Scene::flat): incoherent rays take
+    // different branches of even a four-node tree, which costs more lane time than testing everything in step.
+    bool flat_ok = total_prims <= env_u32("RTAMD_FLAT_MAX", 48);
+    for (uint32_t g = 1; g <= ng; g++)
+        if (members[g].size() > 64) flat_ok = false;
+    // In such a scene a Box2 (six rects, shapes.rs:456-466) becomes ONE record: its six tests share three reciprocals
+    // (cornell_box 32.0 -> 26.1 ms per 64 spp).  A scene that takes the tree keeps its rects: there the box test's
+    // registers cost the walk a resident wave per SIMD, which outweighs the shallower tree (final_scene 120 against
+    // 110 ms per 256 spp), so the tree-walking kernels are compiled without it.  Medium boundaries keep their rects
+    // too (the boundary queries want the separate roots).
+    if (c->fuse_boxes && flat_ok)
         for (uint32_t g = 0; g <= ng; g++)
             if (g == 0 || c->groups[g - 1].kind != RT_GROUP_MEDIUM) fuse_boxes(c, members[g]);
 
@@ -696,9 +703,6 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     std::vector<rtb::Item> top;
     std::vector<uint32_t> media_groups;
     uint32_t blas_depth = 0, n_media = 0, n_inst = 0;
-    // Scenes of a few dozen primitives are traced without the tree (see rtd::Scene::flat): incoherent rays take
-    // different branches of even a four-node tree, which costs more lane time than testing everything in step.
-    bool flat_ok = total_prims <= env_u32("RTAMD_FLAT_MAX", 48);
     // groups first: each gets a contiguous primitive range and (for instances) its own BVH
     for (uint32_t g = 0; g < ng; g++) {
         const rt_group& G = c->groups[g];
@@ -721,7 +725,6 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         // a box record costs six rect tests: size decisions count it as six
         size_t mem_tests = 0;
         for (const PrimSrc& ps : mem) mem_tests += ps.box ? 6 : 1;
-        if (mem_tests > 64) flat_ok = false;
         std::vector<rtb::Item> items(mem.size());
         float glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t i = 0; i < mem.size(); i++) {

@@ -218,6 +218,9 @@ DEV void box_side(float t, float p0, float p1, float min0, float min1, float max
 }
 // Candidate t of one primitive in [tmin, tmax] (inclusive, as the reference's "< t_min || > t_max" rejects).
 // id_out: the caller's id of the primitive that was hit -- for a box, of the side that won.
+// BOXES: box records can occur (only scenes traced without a tree hold them, see rt_scene_commit); the tree walk is
+// compiled without that branch, whose registers would cost it a resident wave per SIMD.
+template <bool BOXES>
 DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out,
                         uint32_t& id_out) {
     const float4* pp = reinterpret_cast<const float4*>(S.prims + pi);
@@ -242,7 +245,7 @@ DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float 
             t = (-half_b + sq) / a;
             if (t < tmin || t > tmax) return false;
         }
-    } else if (kind == PK_BOX) {  // Box2::intersect = Scene::intersect over the six sides (shapes.rs:474-477)
+    } else if (BOXES && kind == PK_BOX) {  // Box2::intersect = Scene::intersect over the six sides (shapes.rs:474-477)
         const f3 lo{A.x, A.y, A.z}, hi{A.w, B.x, B.w};
         float tz0, tz1, ty0, ty1, tx0, tx1;
         float closest = tmax;
@@ -274,10 +277,11 @@ DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float 
 }
 
 // Closest-hit update with the exact-tie rule "higher id wins" (scene.rs:32-38: the later shape wins).
+template <bool BOXES>
 DEV void test_prim(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time, float tmin, int grp, Hit& best) {
     float t;
     uint32_t id;
-    if (!prim_candidate(S, pi, o, d, a, time, tmin, best.t, t, id)) return;
+    if (!prim_candidate<BOXES>(S, pi, o, d, a, time, tmin, best.t, t, id)) return;
     if (t == best.t && best.prim != HIT_NONE && id < best.key) return;
     best.t = t;
     best.prim = pi;
@@ -293,7 +297,7 @@ DEV bool list_closest(const Scene& S, uint32_t ref, f3 o, f3 d, float a, float t
     for (uint32_t i = 0; i < cnt; i++) {
         float t;
         uint32_t id;
-        if (prim_candidate(S, first + i, o, d, a, time, tmin, closest, t, id)) {
+        if (prim_candidate<false>(S, first + i, o, d, a, time, tmin, closest, t, id)) {
             closest = t;
             any = true;
         }
@@ -662,7 +666,7 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
     }
     if (type == REF_PRIMS) {
         uint32_t first = w.cur & 0x03FFFFFFu, n_leaf = ((w.cur >> 26) & 15u) + 1u;
-        for (uint32_t i = 0; i < n_leaf; i++) test_prim(S, first + i, w.o, w.d, w.a, time, tmin, w.grp, w.best);
+        for (uint32_t i = 0; i < n_leaf; i++) test_prim<false>(S, first + i, w.o, w.d, w.a, time, tmin, w.grp, w.best);
         if (COUNT) cnt->prims += n_leaf;
         w.cur = REF_EMPTY;
     } else if (GROUPS && type == REF_INSTANCE) {
@@ -716,7 +720,7 @@ DEV void trace_flat(const Scene& S, f3 wo, f3 wd, float time, float tmin, float 
     best.grp = -1;
     best.key = 0;
     const float a = dot3(wd, wd);
-    for (uint32_t i = 0; i < S.world_count; i++) test_prim(S, S.world_first + i, wo, wd, a, time, tmin, -1, best);
+    for (uint32_t i = 0; i < S.world_count; i++) test_prim<true>(S, S.world_first + i, wo, wd, a, time, tmin, -1, best);
     if (COUNT) cnt->prims += S.world_count;
     if (GROUPS)
         for (uint32_t g = 0; g < S.n_groups; g++) {
@@ -730,16 +734,18 @@ DEV void trace_flat(const Scene& S, f3 wo, f3 wd, float time, float tmin, float 
                 ag = dot3(d, d);
             }
             const uint32_t first = G.flat_range & 0x03FFFFFFu, n = (G.flat_range >> 26) + 1u;
-            for (uint32_t i = 0; i < n; i++) test_prim(S, first + i, o, d, ag, time, tmin, (int)g, best);
+            for (uint32_t i = 0; i < n; i++) test_prim<true>(S, first + i, o, d, ag, time, tmin, (int)g, best);
             if (COUNT) cnt->prims += n;
         }
 }
 // Closest hit of one ray: "while-while" -- the inner loop walks inner nodes only, so that lanes of a wave that
 // are still descending do not drag the (long) primitive tests of the others along on every iteration.
-template <int STRIDE, bool GROUPS, bool COUNT = false>
+// FLAT: the scene is traced without a tree (Scene::flat); a template parameter, so that neither form carries the
+// registers of the other.
+template <int STRIDE, bool GROUPS, bool FLAT, bool COUNT = false>
 DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
                    uint32_t bounce, Hit& best, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
-    if (S.flat) {
+    if (FLAT) {
         trace_flat<GROUPS, COUNT>(S, wo, wd, time, tmin, tmax, best, cnt);
         if (GROUPS) apply_media<COUNT>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
         return;

@@ -221,7 +221,7 @@ DEV uint32_t primary_count(uint32_t n, uint32_t s) {
 
 // Held to 128 VGPRs (4 waves per SIMD): one more resident wave than the compiler's own choice hides more of
 // the queue loads and the compaction barrier than the few spilled values cost.
-template <bool GROUPS, bool COUNT, bool PRIMARY>
+template <bool GROUPS, bool COUNT, bool PRIMARY, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : BOUNCE_WAVES))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
                                                         rtk::PathState out, rtk::Queues q, uint32_t bounce,
                                                         float4* __restrict__ radiance, unsigned long long* stats,
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
                 t0 = t1;
             }
             Hit h;
-            trace_ray<rtk::BLOCK, GROUPS, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk,
+            trace_ray<rtk::BLOCK, GROUPS, FLAT, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk,
                                                         overflow_flag, &tc);
             if (COUNT) {
                 asm volatile("" ::"v"(h.t), "v"(h.prim));
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 5
 #endif
-template <bool GROUPS, bool COUNT>
+template <bool GROUPS, bool COUNT, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES))) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
                                                        uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS, uint32_t lds_entries,
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
     // blockIdx.x * BLOCK + threadIdx.x is this thread's column of the spill area (gridDim.x * BLOCK columns)
     const Stack stk{stack + threadIdx.x, lds_entries, spill + (size_t)blockIdx.x * rtk::BLOCK + threadIdx.x, gridDim.x * (uint32_t)rtk::BLOCK};
     TraceCount tc{0u, 0u, 0u, 0u, 0u};
-    if (S.flat) {  // no tree, no divergence between rays: plain strided loop
+    if (FLAT) {  // no tree, no divergence between rays: plain strided loop
         for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
             const uint32_t at = shard_base + i;
             const float4 ot = in.o_time[at], ds = in.d_slot[at];
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 // read-back of the queue lengths) rather than work, so the remaining paths are finished here in one go:
 // each lane takes one queued path and runs the ray_color loop (main.rs:44-63) to its end.  A path's draws
 // are keyed by (stream, bounce), so the result is the one the bounce-per-launch kernels would have produced.
-template <bool GROUPS>
+template <bool GROUPS, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::Queues q,
                                                         uint32_t bounce, float4* __restrict__ radiance,
                                                         unsigned long long* stats, uint32_t* overflow_flag) {
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
         load_path(in, shard_base + i, p);
         for (uint32_t b = bounce;; b++) {  // shade_path ends the path at the depth limit at the latest
             Hit h;
-            trace_ray<rtk::BLOCK, GROUPS, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, b, h, stk, overflow_flag, nullptr);
+            trace_ray<rtk::BLOCK, GROUPS, FLAT, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, b, h, stk, overflow_flag, nullptr);
             rays++;
             if (!shade_path(S, L, rc, p, h, b, radiance)) break;
         }
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
 // no launch per bounce.  That only pays where every lane of a wave does the same work per bounce -- scenes traced
 // flat; through a tree the lanes' walks diverge and the queue-based kernels, which re-pack rays between the walk
 // and the shading, stay ahead.  Draws are keyed by (stream, bounce): the image is the one the other pipelines give.
-template <bool GROUPS>
+template <bool GROUPS, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : PATHS_WAVES))) void k_paths(
     Scene S, rtk::RenderConst rc, rtk::Batch batch, float4* __restrict__ radiance, unsigned long long* stats,
     uint32_t* overflow_flag, uint32_t REGEN) {
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
             }
             if (have) {
                 Hit h;
-                trace_ray<rtk::BLOCK, GROUPS, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk, overflow_flag, nullptr);
+                trace_ray<rtk::BLOCK, GROUPS, FLAT, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk, overflow_flag, nullptr);
                 rays++;
                 if (shade_path(S, L, rc, p, h, bounce, radiance))
                     bounce++;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_resolve(const float* __restrict_
     }
 }
 
-template <bool GROUPS>
+template <bool GROUPS, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigned long long n, const float* __restrict__ ox,
                                                                  const float* __restrict__ oy, const float* __restrict__ oz,
                                                                  const float* __restrict__ dx, const float* __restrict__ dy,
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
         uint32_t k0, k1;
         stream_key(seed, (uint32_t)i, 0u, k0, k1);
         Hit h;
-        trace_ray<rtk::BLOCK, GROUPS>(S, wo, wd, time, tmin, tmax, k0, k1, 0u, h, stk, overflow_flag);
+        trace_ray<rtk::BLOCK, GROUPS, FLAT>(S, wo, wd, time, tmin, tmax, k0, k1, 0u, h, stk, overflow_flag);
         bool hit = h.prim != HIT_NONE;
         Record rec;
         rec.point = {0, 0, 0};
@@ -719,15 +719,21 @@ inline int grid_sharded(uint32_t blocks_per_shard, const void* fn, int oversub, 
 namespace rtk {
 
 // groups x instrumented -> template instance
-#define RT_DISPATCH_TRACE_CFG(cfg, CALL)                \
-    do {                                                \
-        if ((cfg).has_groups) {                         \
-            if ((cfg).count_visits) CALL(true, true);   \
-            else CALL(true, false);                     \
-        } else {                                        \
-            if ((cfg).count_visits) CALL(false, true);  \
-            else CALL(false, false);                    \
-        }                                               \
+#define RT_DISPATCH_GC(cfg, CALL, F)                       \
+    do {                                                   \
+        if ((cfg).has_groups) {                            \
+            if ((cfg).count_visits) CALL(true, true, F);   \
+            else CALL(true, false, F);                     \
+        } else {                                           \
+            if ((cfg).count_visits) CALL(false, true, F);  \
+            else CALL(false, false, F);                    \
+        }                                                  \
+    } while (0)
+// groups x instrumented x traced-without-a-tree -> template instance
+#define RT_DISPATCH_TRACE_CFG(cfg, flat, CALL)        \
+    do {                                              \
+        if (flat) RT_DISPATCH_GC(cfg, CALL, true);    \
+        else RT_DISPATCH_GC(cfg, CALL, false);        \
     } while (0)
 
 // LDS bytes of the per-lane traversal stacks of one block
@@ -763,9 +769,9 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
     // from.  When few rays are queued, launch fewer blocks rather than shorter runs: at least min_run rays per wave.
     static const int min_run = env_factor("RTAMD_TRACE_MIN_RUN", 16) * 8;  // in units of 8 rays (env_factor caps at 64)
     blocks_per_shard = std::max(1u, (blocks_per_shard * BLOCK + (BLOCK / 64) * min_run - 1) / ((BLOCK / 64) * min_run));
-#define RT_CALL(G, C)                                                                                                            \
+#define RT_CALL(G, C, F)                                                                                                         \
     do {                                                                                                                         \
-        const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C>, trace_oversubscription(), smem);            \
+        const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C, F>, trace_oversubscription(), smem);         \
         const size_t need = (size_t)deep * grid * BLOCK * sizeof(uint32_t);                                                      \
         if (need > spill.bytes) {                                                                                                \
             if (spill.p) (void)hipFree(spill.p);                                                                                 \
@@ -775,11 +781,11 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
             if (e != hipSuccess) return e;                                                                                       \
             spill.bytes = need;                                                                                                  \
         }                                                                                                                        \
-        hipLaunchKernelGGL((k_trace<G, C>), dim3(grid), block, smem, s, scene, in, q, bounce, hits, stats, overflow_flag,        \
+        hipLaunchKernelGGL((k_trace<G, C, F>), dim3(grid), block, smem, s, scene, in, q, bounce, hits, stats, overflow_flag,     \
                            (uint32_t)env_factor("RTAMD_REFILL", 24), env_factor("RTAMD_INNER_STEPS", 4), lds_entries,            \
                            (uint32_t*)spill.p);                                                                                  \
     } while (0)
-    RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
+    RT_DISPATCH_TRACE_CFG(cfg, scene.flat != 0u, RT_CALL);
 #undef RT_CALL
     return hipGetLastError();
 }
@@ -798,18 +804,18 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
     const dim3 block(BLOCK);
     const size_t smem = stack_bytes(scene) + table_bytes(scene);
     if (bounce == 0) {
-#define RT_CALL(G, C)                                                                                                     \
-    hipLaunchKernelGGL((k_bounce<G, C, true>),                                                                            \
-                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, true>, oversubscription(), smem)), block, \
+#define RT_CALL(G, C, F)                                                                                                  \
+    hipLaunchKernelGGL((k_bounce<G, C, true, F>),                                                                         \
+                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, true, F>, oversubscription(), smem)), block, \
                        smem, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
-        RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
+        RT_DISPATCH_TRACE_CFG(cfg, scene.flat != 0u, RT_CALL);
 #undef RT_CALL
     } else {
-#define RT_CALL(G, C)                                                                                                      \
-    hipLaunchKernelGGL((k_bounce<G, C, false>),                                                                            \
-                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, false>, oversubscription(), smem)), block, \
+#define RT_CALL(G, C, F)                                                                                                   \
+    hipLaunchKernelGGL((k_bounce<G, C, false, F>),                                                                         \
+                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, false, F>, oversubscription(), smem)), block, \
                        smem, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
-        RT_DISPATCH_TRACE_CFG(cfg, RT_CALL);
+        RT_DISPATCH_TRACE_CFG(cfg, scene.flat != 0u, RT_CALL);
 #undef RT_CALL
     }
     return hipGetLastError();
@@ -822,10 +828,15 @@ hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
     if (blocks_per_shard < 1) blocks_per_shard = 1;
     if (blocks_per_shard > (uint32_t)MAX_BLOCKS_PER_SHARD) blocks_per_shard = MAX_BLOCKS_PER_SHARD;
     const dim3 grid(blocks_per_shard * NSHARD), block(BLOCK);
-    if (cfg.has_groups)
-        hipLaunchKernelGGL((k_finish<true>), grid, block, smem, s, scene, rc, in, q, bounce, radiance, stats, overflow_flag);
-    else
-        hipLaunchKernelGGL((k_finish<false>), grid, block, smem, s, scene, rc, in, q, bounce, radiance, stats, overflow_flag);
+#define RT_FINISH(G, F) hipLaunchKernelGGL((k_finish<G, F>), grid, block, smem, s, scene, rc, in, q, bounce, radiance, stats, overflow_flag)
+    if (cfg.has_groups) {
+        if (scene.flat) RT_FINISH(true, true);
+        else RT_FINISH(true, false);
+    } else {
+        if (scene.flat) RT_FINISH(false, true);
+        else RT_FINISH(false, false);
+    }
+#undef RT_FINISH
     return hipGetLastError();
 }
 
@@ -839,19 +850,22 @@ hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
     // so short that the lanes idling while its last paths drain (up to max_depth bounces) weigh against it.
     static const unsigned long long run = 24ull * (unsigned long long)env_factor("RTAMD_PATHS_RUN", 64);  // units of 24 slots
     const unsigned long long want = (n + (BLOCK / 64) * run - 1) / ((BLOCK / 64) * run);
-#define RT_PATHS(G)                                                                                                         \
+#define RT_PATHS(G, F)                                                                                                      \
     do {                                                                                                                    \
-        const unsigned long long fit = resident_blocks((const void*)&k_paths<G>, smem);                                     \
+        const unsigned long long fit = resident_blocks((const void*)&k_paths<G, F>, smem);                                  \
         const unsigned long long all = (n + BLOCK - 1) / BLOCK;                                                             \
         /* small batches: 16 rounds of blocks if that leaves runs of 512 slots, for balance */                              \
         const unsigned long long small = std::min(16 * fit, (n + (BLOCK / 64) * 512ull - 1) / ((BLOCK / 64) * 512ull));     \
         const dim3 grid((uint32_t)std::max<unsigned long long>(1, std::min(all, std::min(std::max({want, fit, small}), 1ull << 20)))); \
-        hipLaunchKernelGGL((k_paths<G>), grid, dim3(BLOCK), smem, s, scene, rc, batch, radiance, stats, overflow_flag, regen); \
+        hipLaunchKernelGGL((k_paths<G, F>), grid, dim3(BLOCK), smem, s, scene, rc, batch, radiance, stats, overflow_flag, regen); \
     } while (0)
-    if (cfg.has_groups)
-        RT_PATHS(true);
-    else
-        RT_PATHS(false);
+    if (cfg.has_groups) {
+        if (scene.flat) RT_PATHS(true, true);
+        else RT_PATHS(true, false);
+    } else {
+        if (scene.flat) RT_PATHS(false, true);
+        else RT_PATHS(false, false);
+    }
 #undef RT_PATHS
     return hipGetLastError();
 }
@@ -891,11 +905,11 @@ hipError_t launch_intersect_batch(hipStream_t s, const TraceCfg& cfg, const Scen
     const dim3 grid(grid_flat(n)), block(BLOCK);
     TraceCfg c = cfg;
     c.count_visits = false;
-#define RT_CALL(G, C)                                                                                                          \
-    hipLaunchKernelGGL((k_intersect_batch<G>), grid, block, stack_bytes(scene), s, scene, (unsigned long long)n, rays[0], rays[1], \
+#define RT_CALL(G, C, F)                                                                                                       \
+    hipLaunchKernelGGL((k_intersect_batch<G, F>), grid, block, stack_bytes(scene), s, scene, (unsigned long long)n, rays[0], rays[1], \
                        rays[2], rays[3], rays[4], rays[5], rays[6], tmin, tmax, seed, prim, inst, t, normal, front, uv, point,  \
                        overflow_flag)
-    RT_DISPATCH_TRACE_CFG(c, RT_CALL);
+    RT_DISPATCH_TRACE_CFG(c, scene.flat != 0u, RT_CALL);
 #undef RT_CALL
     return hipGetLastError();
 }
