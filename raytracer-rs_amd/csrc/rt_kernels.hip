@@ -354,7 +354,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
     const uint32_t end = __builtin_amdgcn_readfirstlane(next + per < n ? next + per : n);
     bool have = false;
     uint32_t idx = 0;
-    f3 wo{0, 0, 0}, wd{0, 0, 0};
+    f3 wo{0, 0, 0}, wd{0, 0, 0};  // the world ray (used only when the scene has instances)
     float time = 0.0f;
     Walk w;
     walk_begin(S, w, wo, wd, INF_F);
@@ -392,7 +392,12 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
         }
         if (have) {
             walk_inner<rtk::BLOCK, COUNT>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
-            walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, wo, wd, time, 0.005f, stk, overflow_flag, &tc);
+            // (without instances the walk never leaves world space: its own copy of the ray is the world ray, and keeping
+            // a second one would cost the kernel a resident wave per SIMD)
+            if (GROUPS)
+                walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, wo, wd, time, 0.005f, stk, overflow_flag, &tc);
+            else
+                walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
             if (walk_done(w)) {
                 hits[idx] = make_float4(w.best.t, __uint_as_float(w.best.prim), __int_as_float(w.best.grp), __uint_as_float(w.best.key));
                 have = false;
