@@ -313,7 +313,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
 }
 
 #ifndef TRACE_WAVES
-#define TRACE_WAVES 5
+#define TRACE_WAVES 7
 #endif
 template <bool GROUPS, bool COUNT, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES))) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
@@ -354,7 +354,10 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
     const uint32_t end = __builtin_amdgcn_readfirstlane(next + per < n ? next + per : n);
     bool have = false;
     uint32_t idx = 0;
-    f3 wo{0, 0, 0}, wd{0, 0, 0};  // the world ray (used only when the scene has instances)
+    f3 wo{0, 0, 0}, wd{0, 0, 0};
+    // With instances the world ray is needed again wherever the walk enters or leaves one.  It waits in this lane's own
+    // LDS words behind the stacks ([component][lane]) rather than in six registers: those cost a resident wave per SIMD.
+    float* world_ray = reinterpret_cast<float*>(stack + (size_t)lds_entries * rtk::BLOCK) + threadIdx.x;
     float time = 0.0f;
     Walk w;
     walk_begin(S, w, wo, wd, INF_F);
@@ -377,6 +380,14 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
                 wo = mk3(ot.x, ot.y, ot.z);
                 wd = mk3(ds.x, ds.y, ds.z);
                 time = ot.w;
+                if (GROUPS) {
+                    world_ray[0 * rtk::BLOCK] = wo.x;
+                    world_ray[1 * rtk::BLOCK] = wo.y;
+                    world_ray[2 * rtk::BLOCK] = wo.z;
+                    world_ray[3 * rtk::BLOCK] = wd.x;
+                    world_ray[4 * rtk::BLOCK] = wd.y;
+                    world_ray[5 * rtk::BLOCK] = wd.z;
+                }
                 walk_begin(S, w, wo, wd, INF_F);
                 have = true;
                 if (COUNT) {
@@ -394,10 +405,18 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
             walk_inner<rtk::BLOCK, COUNT>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
             // (without instances the walk never leaves world space: its own copy of the ray is the world ray, and keeping
             // a second one would cost the kernel a resident wave per SIMD)
-            if (GROUPS)
-                walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, wo, wd, time, 0.005f, stk, overflow_flag, &tc);
-            else
+            if (GROUPS) {
+                const uint32_t type = w.cur >> 30;
+                if (w.cur != REF_EMPTY && type != REF_INNER && type != REF_PRIMS) {  // instance or sentinel
+                    const f3 lo = mk3(world_ray[0 * rtk::BLOCK], world_ray[1 * rtk::BLOCK], world_ray[2 * rtk::BLOCK]);
+                    const f3 ld = mk3(world_ray[3 * rtk::BLOCK], world_ray[4 * rtk::BLOCK], world_ray[5 * rtk::BLOCK]);
+                    walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, lo, ld, time, 0.005f, stk, overflow_flag, &tc);
+                } else {
+                    walk_leaf<rtk::BLOCK, false, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
+                }
+            } else {
                 walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
+            }
             if (walk_done(w)) {
                 hits[idx] = make_float4(w.best.t, __uint_as_float(w.best.prim), __int_as_float(w.best.grp), __uint_as_float(w.best.key));
                 have = false;
@@ -768,7 +787,8 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
                         SpillArea& spill) {
     const dim3 block(BLOCK);
     const uint32_t lds_entries = trace_lds_entries(scene);
-    const size_t smem = (size_t)lds_entries * BLOCK * sizeof(uint32_t);
+    // stacks, then (scenes with instances) each lane's world ray
+    const size_t smem = (size_t)lds_entries * BLOCK * sizeof(uint32_t) + (cfg.has_groups ? (size_t)BLOCK * 6 * sizeof(float) : 0);
     const uint32_t deep = std::max(1u, scene.stack_cap) - lds_entries;
     // A wave refills its free lanes from its own run of the queue, so a run of one tile gives it nothing to refill
     // from.  When few rays are queued, launch fewer blocks rather than shorter runs: at least min_run rays per wave.
