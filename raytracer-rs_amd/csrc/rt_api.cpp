@@ -1467,6 +1467,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     rcst.height = p->height;
     rcst.seed = p->seed;
     rcst.max_depth = p->max_depth;
+    rcst.radiance_cleared = (p->background[0] == 0.0f && p->background[1] == 0.0f && p->background[2] == 0.0f) ? 1u : 0u;
 
     rt_render_stats st{};
     c->ev_used.clear();
@@ -1514,6 +1515,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 uint32_t bps = (n_batch + rtk::BLOCK * rtk::NSHARD - 1) / (rtk::BLOCK * rtk::NSHARD);
                 st.batches++;
                 st.paths += n_batch;
+                if (rcst.radiance_cleared) HIP_TRY(c, hipMemsetAsync(d_rad, 0, (size_t)n_batch * sizeof(float4), c->stream));
                 if (mode == 3 && !c->count_visits) {
                     // whole paths with regeneration: one launch, nothing queued
                     {

@@ -35,6 +35,10 @@ struct RenderConst {
     uint32_t width, height;
     uint32_t seed;
     uint32_t max_depth;
+    // != 0: the radiance buffer of the batch was cleared before the first bounce, and a path that ends with zero
+    // radiance writes nothing.  rt_render sets it when the background is black: then nearly every path ends that way,
+    // and one streaming clear is far cheaper than a scattered 16-byte write per path.
+    uint32_t radiance_cleared;
 };
 
 // one wavefront batch: npix pixels (pixel_list) x n_samples samples starting at sample0

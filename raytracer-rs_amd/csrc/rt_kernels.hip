@@ -108,11 +108,16 @@ DEV void store_path(const rtk::PathState& st, uint32_t idx, const PathRegs& p) {
 
 // One step of ray_color (main.rs:44-63) after the hit is known.  Returns true when the path goes on (p is
 // then the scattered ray with the updated throughput); otherwise its radiance has been written.
+// Radiance of a path that has ended.  Adding a zero (of either sign) to a pixel's sum changes nothing, so zeros are
+// not written when the buffer starts out cleared.
+DEV void end_path(const rtk::RenderConst& rc, float4* __restrict__ radiance, uint32_t slot, f3 L) {
+    if (rc.radiance_cleared && L.x == 0.0f && L.y == 0.0f && L.z == 0.0f) return;
+    radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+}
 DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderConst& rc, PathRegs& p, const Hit& h, uint32_t bounce,
                     float4* __restrict__ radiance) {
     if (h.prim == HIT_NONE) {  // main.rs:60-62
-        f3 L = p.T * ld3(rc.background);
-        radiance[p.slot] = make_float4(L.x, L.y, L.z, 0.0f);
+        end_path(rc, radiance, p.slot, p.T * ld3(rc.background));
         return false;
     }
     // material first, so that uv (acos/atan2) is only evaluated for textures that read it
@@ -136,7 +141,7 @@ DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderCons
     const f3 color = material_color(S, tabs, M, rec);
     if (scatter(M, color, p.d, rec, rng, att, dir)) {
         if (bounce + 1u >= rc.max_depth) {  // main.rs:45-47: the next ray_color call returns zero
-            radiance[p.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            end_path(rc, radiance, p.slot, mk3(0.0f, 0.0f, 0.0f));
             return false;
         }
         p.T = p.T * att;
@@ -146,8 +151,7 @@ DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderCons
     }
     f3 E{0.0f, 0.0f, 0.0f};  // main.rs:57-59
     if (M.kind == MK_LIGHT) E = color;
-    f3 L = p.T * E;
-    radiance[p.slot] = make_float4(L.x, L.y, L.z, 0.0f);
+    end_path(rc, radiance, p.slot, p.T * E);
     return false;
 }
 
