@@ -5,7 +5,8 @@ import torch, rtamd
 name = sys.argv[1]; pipe = int(sys.argv[2]); w = int(sys.argv[3]); spp = int(sys.argv[4])
 aspect = 1.0 if name.startswith(("cornell", "final")) else 16 / 9
 ctx = rtamd.Context(0)
-ctx.load_scene(name, seed=1)
+n_synth = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+ctx.load_scene(name, seed=1, **({'n_synth': n_synth} if n_synth else {}))
 ctx.set_pipeline(pipe)
 h = rtamd.image_height(w, aspect)
 acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
