@@ -191,11 +191,11 @@ DEV void box_side_rect(float4 A, float4 B, uint32_t side, uint32_t& kind, float&
     max0 = comp(hi, a0);
     max1 = comp(hi, a1);
 }
-// (k0 - o) / d and (k1 - o) / d, the plane distances of two parallel sides (shapes.rs:280, 344, 408).  Both
-// quotients share the denominator, so they come from one refined reciprocal (bit-identical to the IEEE
-// division inside the window of div_by; a numerator that is tiny but not zero takes the plain division).
-DEV void plane_pair(float k0, float k1, float o, float d, float& t0, float& t1) {
-    const float n0 = k0 - o, n1 = k1 - o;
+// n0 / d and n1 / d -- (k0 - o) / d and (k1 - o) / d, the plane distances of two parallel sides (shapes.rs:280,
+// 344, 408), or the two roots of a sphere (shapes.rs:126, 131).  Both quotients share the denominator, so they come
+// from one refined reciprocal (bit-identical to the IEEE division inside the window of div_by; a numerator that
+// is tiny but not zero takes the plain division).
+DEV void quotient_pair(float n0, float n1, float d, float& t0, float& t1) {
     const float big = fmaxf(__builtin_fabsf(n0), __builtin_fabsf(n1));
     const float small = fminf(n0 == 0.0f ? 1.0f : __builtin_fabsf(n0), n1 == 0.0f ? 1.0f : __builtin_fabsf(n1));
     if (in_div_window(d) && big < 0x1p60f && small > 0x1p-60f) {
@@ -207,6 +207,7 @@ DEV void plane_pair(float k0, float k1, float o, float d, float& t0, float& t1) 
         t1 = n1 / d;
     }
 }
+DEV void plane_pair(float k0, float k1, float o, float d, float& t0, float& t1) { quotient_pair(k0 - o, k1 - o, d, t0, t1); }
 // One rect side inside Scene::intersect over the box's sides (scene.rs:27-41): accepted when t lies in
 // [tmin, closest] and the in-plane point inside the bounds, all inclusive; a later side with the same t wins.
 DEV void box_side(float t, float p0, float p1, float min0, float min1, float max0, float max1, float tmin, uint32_t s, float& closest,
@@ -326,8 +327,7 @@ DEV uint32_t prim_roots(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float 
         float disc = half_b * half_b - a * cc;
         if (disc < 0.0f) return 0u;
         float sq = __builtin_sqrtf(disc);
-        c0 = (-half_b - sq) / a;
-        c1 = (-half_b + sq) / a;
+        quotient_pair(-half_b - sq, -half_b + sq, a, c0, c1);
         return 3u;
     }
     int ax = kind == PK_RECT_XY ? 2 : (kind == PK_RECT_XZ ? 1 : 0);  // shapes.rs:279-292, 343-356, 407-420
@@ -394,13 +394,14 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
         o = xf_point(G.minv, wo);
         d = xf_vector(G.minv, wd);
     }
-    // The first boundary query runs over the whole line (shapes.rs:655); a line that misses the widened box
-    // of the boundary misses every primitive of it, so the exact tests are skipped for it.
-    float tn_unused;
-    if (!slab(ld3(G.blo), ld3(G.bhi), o, fast_rcp3(d), -INF_F, INF_F, tn_unused)) return;
     float a = dot3(d, d);
     float r1, r2;
     const uint32_t first = G.root_ref & 0x03FFFFFFu, cnt = ((G.root_ref >> 26) & 15u) + 1u;
+    // The first boundary query runs over the whole line (shapes.rs:655); a line that misses the widened box
+    // of the boundary misses every primitive of it, so the exact tests are skipped for it.  (A single primitive
+    // rejects a line that misses it as early as the box would.)
+    float tn_unused;
+    if (cnt > 1u && !slab(ld3(G.blo), ld3(G.bhi), o, fast_rcp3(d), -INF_F, INF_F, tn_unused)) return;
     if (cnt == 1u) {
         // one primitive (a sphere in every reference scene, main.rs:226-235, 281-284): the first query over the whole
         // line takes the primitive's first candidate, the second query from r1 + 0.0001 on the first candidate at or
@@ -419,7 +420,7 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     if (r2 > best.t) r2 = best.t;
     if (r1 >= r2) return;
     if (r1 < 0.0f) r1 = 0.0f;
-    double len = (double)len3(wd);
+    double len = (double)(G.has_xform ? len3(wd) : __builtin_sqrtf(a));  // (without a transform a is |wd|^2 already)
     double inside = (double)(r2 - r1) / len;
     double xi = medium_xi(k0, k1, bounce, G.order);
 #ifdef EXP_F32_LOG
