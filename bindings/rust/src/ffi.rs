@@ -60,7 +60,8 @@ pub struct rt_group {
     pub minv: [f32; 12],
     pub neg_inv_density: f64,
     pub mat: u32,
-    pub reserved: u32,
+    /// 0: in the world; otherwise 1 + index of the instance group this one stands inside
+    pub parent: u32,
 }
 #[repr(C)]
 #[derive(Default, Clone, Copy)]

@@ -99,8 +99,9 @@ impl FlatScene {
         self.rect_id.push(id);
         self.rect_group.push(group);
     }
-    fn add_group(&mut self, kind: u32, xform: Option<(Mat4, Mat4)>, neg_inv_density: f64, mat: u32) -> u32 {
-        let mut g = rt_group { kind, neg_inv_density, mat, ..Default::default() };
+    /// parent: 0, or the group (1 + index) of the TransformedObject this one stands inside
+    fn add_group(&mut self, kind: u32, xform: Option<(Mat4, Mat4)>, neg_inv_density: f64, mat: u32, parent: u32) -> u32 {
+        let mut g = rt_group { kind, neg_inv_density, mat, parent, ..Default::default() };
         if let Some((m, minv)) = xform {
             g.has_xform = 1;
             g.m = rows3x4(&m);
@@ -173,8 +174,9 @@ pub fn check(ctx: *mut rt_ctx, rc: i32) -> Result<(), String> {
 //     fn flatten(&self, fs: &mut FlatScene, group: u32) { self.sides.flatten(fs, group) }
 // impl<T: Hittable> Hittable for TransformedObject<T> (shapes.rs:64):
 //     fn flatten(&self, fs: &mut FlatScene, group: u32) {
-//         assert_eq!(group, 0, "TransformedObject nested inside another group is not supported on the device");
-//         let g = fs.add_group(RT_GROUP_INSTANCE, Some((self.transform, self.inv_transform)), 0.0, 0);
+//         // inside another TransformedObject: parent = that group (the library takes up to 4 stacked instances and
+//         // refuses one inside a medium's boundary with RT_ERR_UNSUPPORTED at rt_scene_commit)
+//         let g = fs.add_group(RT_GROUP_INSTANCE, Some((self.transform, self.inv_transform)), 0.0, 0, group);
 //         self.object.flatten(fs, g);
 //     }
 //     fn as_transformed(&self) -> Option<(Mat4, Mat4, &dyn Hittable)> {
@@ -187,9 +189,9 @@ pub fn check(ctx: *mut rt_ctx, rc: i32) -> Result<(), String> {
 //         assert_eq!(group, 0, "ConstantMedium nested inside another group is not supported on the device");
 //         let mat = fs.material(&self.material);                      // the Isotropic phase function
 //         match self.boundary.as_transformed() {
-//             Some((m, minv, inner)) => { let g = fs.add_group(RT_GROUP_MEDIUM, Some((m, minv)), self.negative_density, mat);
+//             Some((m, minv, inner)) => { let g = fs.add_group(RT_GROUP_MEDIUM, Some((m, minv)), self.negative_density, mat, 0);
 //                                         inner.flatten(fs, g); }
-//             None => { let g = fs.add_group(RT_GROUP_MEDIUM, None, self.negative_density, mat);
+//             None => { let g = fs.add_group(RT_GROUP_MEDIUM, None, self.negative_density, mat, 0);
 //                       self.boundary.flatten(fs, g); }
 //         }
 //     }

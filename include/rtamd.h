@@ -109,7 +109,11 @@ typedef struct rt_group {
     float minv[12];          /* world->object */
     double neg_inv_density;  /* media: -1/density in f64 (shapes.rs:642) */
     uint32_t mat;            /* media: the Isotropic phase material */
-    uint32_t reserved;
+    /* 0: the group stands in the world.  Otherwise 1 + index of the instance group it stands inside
+     * (TransformedObject<T> takes any Hittable, shapes.rs:26-41: a transformed object inside a transformed object).
+     * The enclosing group comes earlier in the array and is an instance; at most 4 instances are stacked.  A
+     * primitive's `group` names the innermost instance around it.  Media cannot be nested (RT_ERR_UNSUPPORTED). */
+    uint32_t parent;
 } rt_group;
 
 int rt_scene_clear(rt_ctx* ctx);

@@ -1153,6 +1153,32 @@ void build_cornell_smoke(orc_scene& S) {  // src/main.rs:207-238
     S.world.add_shape(mk<ConstantMedium>(cornell_block(165, 330, 165, 15.0f, v3(265, 0, 305)), 0.5f, v3(0, 0, 0)));
     cornell_camera(S);
 }
+// Not a reference preset: transformed objects inside transformed objects (TransformedObject<T: Hittable>,
+// src/shapes.rs:26-41), up to four deep, in the Cornell shell.  Mirrors nested_instances() of the host library.
+void build_nested_instances(orc_scene& S, Stream& axis_rng) {
+    cornell_walls(S.world, v3(15, 15, 15), 213.0f, 227.0f, 343.0f, 332.0f);
+    V3 white{0.73f, 0.73f, 0.73f};
+    {
+        HPtr box = mk<Box2>(v3(0, 0, 0), v3(165, 165, 165), mk<LambertianMat>(white));
+        HPtr turned = mk<TransformedObject>(box, m4_rotation_y(degree_to_rad(-18.0f)));
+        S.world.add_shape(mk<TransformedObject>(turned, m4_translation(v3(130, 0, 65))));
+    }
+    Scene inner;
+    inner.add_shape(mk<Sphere>(v3(60, 200, 60), 40.0f, mk<MetalMat>(v3(0.8f, 0.85f, 0.88f), 0.0f)));
+    {
+        HPtr box = mk<Box2>(v3(0, 0, 0), v3(80, 80, 80), mk<LambertianMat>(v3(0.65f, 0.05f, 0.05f)));
+        HPtr turned = mk<TransformedObject>(box, m4_rotation_y(degree_to_rad(30.0f)));
+        inner.add_shape(mk<TransformedObject>(turned, m4_translation(v3(20, 120, 20))));
+    }
+    {
+        HPtr ball = mk<Sphere>(v3(0, 0, 0), 30.0f, mk<DielectricMat>(1.5f));
+        inner.add_shape(mk<TransformedObject>(ball, m4_translation(v3(120, 60, 100))));
+    }
+    inner.add_shape(mk<Box2>(v3(0, 0, 0), v3(165, 100, 165), mk<LambertianMat>(white)));
+    HPtr turned = mk<TransformedObject>(BVHNode::from_scene(inner, 0.0f, 1.0f, axis_rng), m4_rotation_y(degree_to_rad(15.0f)));
+    S.world.add_shape(mk<TransformedObject>(turned, m4_translation(v3(265, 0, 295))));
+    cornell_camera(S);
+}
 void build_final_scene(orc_scene& S, Stream& rng, Stream& axis_rng, const uint8_t* img, int iw, int ih) {  // src/main.rs:240-305
     Scene& s = S.world;
     Scene boxes;
@@ -1301,6 +1327,8 @@ orc_scene* orc_scene_create(const char* name, uint32_t seed, const uint8_t* img,
         build_cornell_box(*S);
     else if (n == "cornell_smoke")
         build_cornell_smoke(*S);
+    else if (n == "nested_instances")
+        build_nested_instances(*S, axis);
     else if (n == "final_scene")
         build_final_scene(*S, rng, axis, img, iw, ih);
     else if (n == "synth_spheres")

@@ -663,6 +663,23 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     }
     for (const rt_group& g : c->groups)
         if (g.kind == RT_GROUP_MEDIUM && g.mat >= nm) return fail(c, RT_ERR_INVALID, "medium: material out of range");
+    // Instances inside instances (rt_group::parent): the enclosing group comes first in the array, is an instance
+    // itself, and at most MAX_NESTING instances are stacked.  Media stay at the top level.
+    std::vector<uint32_t> nest_depth(ng, 0);
+    std::vector<std::vector<uint32_t>> children(ng);
+    bool nested = false;
+    for (uint32_t g = 0; g < ng; g++) {
+        const rt_group& G = c->groups[g];
+        if (G.parent == 0) continue;
+        if (G.parent > g) return fail(c, RT_ERR_INVALID, "group: parent must be a group earlier in the array");
+        const rt_group& P = c->groups[G.parent - 1];
+        if (G.kind == RT_GROUP_MEDIUM) return fail(c, RT_ERR_UNSUPPORTED, "a medium nested inside another group is not supported");
+        if (P.kind != RT_GROUP_INSTANCE) return fail(c, RT_ERR_UNSUPPORTED, "an instance nested inside a medium boundary is not supported");
+        nest_depth[g] = nest_depth[G.parent - 1] + 1;
+        if (nest_depth[g] >= rtd::MAX_NESTING) return fail(c, RT_ERR_UNSUPPORTED, "instances nested more than 4 deep");
+        children[G.parent - 1].push_back(g);
+        nested = true;
+    }
 
     // bucket primitives by group, in id order inside a group (Scene::intersect order for medium boundaries)
     std::vector<std::vector<PrimSrc>> members(ng + 1);
@@ -675,6 +692,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     bool flat_ok = total_prims <= env_u32("RTAMD_FLAT_MAX", 48);
     for (uint32_t g = 1; g <= ng; g++)
         if (members[g].size() > 64) flat_ok = false;
+    if (nested) flat_ok = false;  // (the loop that stands in for the tree takes every instance's ray from the world ray)
     // In such a scene a Box2 (six rects, shapes.rs:456-466) becomes ONE record: its six tests share three reciprocals
     // (cornell_box 32.0 -> 26.1 ms per 64 spp).  A scene that takes the tree keeps its rects: there the box test's
     // registers cost the walk a resident wave per SIMD, which outweighs the shallower tree (final_scene 120 against
@@ -702,12 +720,20 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
 
     std::vector<rtb::Item> top;
     std::vector<uint32_t> media_groups;
-    uint32_t blas_depth = 0, n_media = 0, n_inst = 0;
-    // groups first: each gets a contiguous primitive range and (for instances) its own BVH
-    for (uint32_t g = 0; g < ng; g++) {
+    uint32_t blas_depth = 0, blas_depth_wide = 0, n_media = 0, n_inst = 0;
+    // stack entries the walk of an instance can need from its root down, instances inside it included (binary / four-child walk)
+    std::vector<uint32_t> chain_bin(ng, 0), chain_wide(ng, 0);
+    std::vector<rtb::Item> group_item(ng);  // the leaf that stands for the group in the tree around it
+    std::vector<uint8_t> group_has_item(ng, 0);
+    for (uint32_t g = 0; g < ng; g++) dgroups[g].order = c->groups[g].kind == RT_GROUP_MEDIUM ? n_media++ : n_inst++;
+    // groups first: each gets a contiguous primitive range and (for instances) its own BVH.  Last to first, so that
+    // the instances inside an instance (which come after it) are there when its tree is built.
+    for (uint32_t g = ng; g-- > 0;) {
         const rt_group& G = c->groups[g];
         const auto& mem = members[g + 1];
         rtd::Group& D = dgroups[g];
+        D.parent = (int32_t)G.parent - 1;
+        D.depth = nest_depth[g];
         memcpy(D.m, G.m, sizeof(D.m));
         memcpy(D.minv, G.minv, sizeof(D.minv));
         D.neg_inv_density = G.neg_inv_density;
@@ -720,8 +746,6 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
             D.blo[k] = INFINITY;   // empty group: nothing can be hit
             D.bhi[k] = -INFINITY;
         }
-        D.order = G.kind == RT_GROUP_MEDIUM ? n_media++ : n_inst++;
-        if (mem.empty()) continue;
         // a box record costs six rect tests: size decisions count it as six
         size_t mem_tests = 0;
         for (const PrimSrc& ps : mem) mem_tests += ps.box ? 6 : 1;
@@ -731,25 +755,39 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
             prim_box(mem[i], items[i].lo, items[i].hi);
             items[i].payload = (uint32_t)i;
             items[i].type = rtd::REF_PRIMS;
-            for (int k = 0; k < 3; k++) {
-                glo[k] = std::min(glo[k], items[i].lo[k]);
-                ghi[k] = std::max(ghi[k], items[i].hi[k]);
-            }
         }
+        uint32_t below_bin = 0, below_wide = 0;  // the deepest instance inside this one, its sentinel included
+        for (uint32_t ch : children[g])
+            if (group_has_item[ch]) {
+                items.push_back(group_item[ch]);
+                below_bin = std::max(below_bin, 1 + chain_bin[ch]);
+                below_wide = std::max(below_wide, 1 + chain_wide[ch]);
+            }
+        if (items.empty()) continue;
+        for (const rtb::Item& it : items)
+            for (int k = 0; k < 3; k++) {
+                glo[k] = std::min(glo[k], it.lo[k]);
+                ghi[k] = std::max(ghi[k], it.hi[k]);
+            }
         const bool medium = G.kind == RT_GROUP_MEDIUM;
         if (medium && mem.size() > rtd::MAX_LEAF_PRIMS)
             return fail(c, RT_ERR_UNSUPPORTED, "medium boundary with more than 16 primitives");
         if (medium && media_groups.size() >= 64) return fail(c, RT_ERR_UNSUPPORTED, "more than 64 media");
-        const bool single = medium || mem_tests <= 8;
+        const bool single = medium || (mem_tests <= 8 && items.size() == mem.size());
         std::vector<uint32_t> order;
         const uint32_t base = (uint32_t)prims.size();
         rtb::Result r = rtb::build(items, leaf_max, single, base, nodes, order);
         for (uint32_t oi : order) prims.push_back(make_prim(c, mem[oi], moving));
         D.root_ref = r.root_ref;
-        if (mem.size() <= 64) D.flat_range = base | ((uint32_t)(mem.size() - 1) << 26);
+        if (!mem.empty() && mem.size() <= 64) D.flat_range = base | ((uint32_t)(mem.size() - 1) << 26);
         memcpy(D.blo, glo, sizeof(glo));
         memcpy(D.bhi, ghi, sizeof(ghi));
-        if (!medium) blas_depth = std::max(blas_depth, r.depth);
+        chain_bin[g] = r.depth + below_bin;
+        chain_wide[g] = 3u * ((r.depth + 1) / 2) + below_wide;
+        if (!medium && G.parent == 0) {
+            blas_depth = std::max(blas_depth, chain_bin[g]);
+            blas_depth_wide = std::max(blas_depth_wide, chain_wide[g]);
+        }
         rtb::Item it;
         if (G.has_xform) {
             xform_box(G.m, glo, ghi, it.lo, it.hi);
@@ -760,11 +798,17 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         }
         it.payload = g;
         it.type = rtd::REF_INSTANCE;
-        if (medium)
+        if (medium) {
             media_groups.push_back(g);  // evaluated after the BVH walk, not a leaf
-        else
+        } else if (G.parent) {
+            group_item[g] = it;
+            group_has_item[g] = 1;
+        } else {
             top.push_back(it);
+        }
     }
+    std::reverse(media_groups.begin(), media_groups.end());  // (collected last to first) creation order
+    std::reverse(top.begin(), top.end());
     // top level: world primitives + groups
     const auto& world = members[0];
     const size_t n_group_items = top.size();
@@ -912,7 +956,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     if (need > 64) return fail(c, RT_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack");
     // Four-child walk: a node covers two binary levels and leaves up to three entries behind.  The top level, the
     // device-built world tree and the instances' trees are widened separately (each from its own root).
-    const uint32_t need_wide = 3u * ((top_r.depth + 1) / 2 + (lbvh_depth + 1) / 2 + (n_inst ? (blas_depth + 1) / 2 : 0)) + (n_inst ? 1 : 0) + 1;
+    const uint32_t need_wide = 3u * ((top_r.depth + 1) / 2 + (lbvh_depth + 1) / 2) + (n_inst ? 1 + blas_depth_wide : 0) + 1;
     const bool want_wide = c->bvh_width == 4 || (c->bvh_width < 0 && n_nodes_total >= c->wide_min_nodes);
     const bool wide = want_wide && !flat_ok && n_nodes_total > 0 && need_wide <= 64;
     if (wide) {
@@ -1007,6 +1051,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     // is not evaluated (its Group::order still counts it, which keeps the other media's RNG salts where they were)
     S.n_media = (uint32_t)media_groups.size();
     S.flat = flat_ok ? 1u : 0u;
+    S.nested = nested ? 1u : 0u;
     S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
     c->n_perlin_tables = n_perlin;
     S.n_perlin = env_u32("RTAMD_LDS_TABLES", 1) ? n_perlin : 0u;  // 0: noise lookups read the table from global memory
@@ -1072,7 +1117,7 @@ int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, 
     if ((rc = ensure(c, c->d_overflow, 16))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
     if (dev) {
-        HIP_TRY(c, rtk::launch_intersect_batch(c->stream, rtk::TraceCfg{c->stack_entries, c->has_groups, false}, c->scene, n, in, tmin, tmax,
+        HIP_TRY(c, rtk::launch_intersect_batch(c->stream, rtk::TraceCfg{c->stack_entries, c->has_groups, false, c->scene.nested != 0u}, c->scene, n, in, tmin, tmax,
                                                seed, prim, inst, t, normal, front, uv, point, (uint32_t*)c->d_overflow.p));
     } else {
         // staging for host callers: rays in, requested outputs back
@@ -1099,7 +1144,7 @@ int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, 
         float* d_uv = (float*)(o + 28 * n);
         float* d_point = (float*)(o + 36 * n);
         if (e == hipSuccess)
-            e = rtk::launch_intersect_batch(c->stream, rtk::TraceCfg{c->stack_entries, c->has_groups, false}, c->scene, n, drays, tmin, tmax, seed,
+            e = rtk::launch_intersect_batch(c->stream, rtk::TraceCfg{c->stack_entries, c->has_groups, false, c->scene.nested != 0u}, c->scene, n, drays, tmin, tmax, seed,
                                             prim ? d_prim : nullptr, inst ? d_inst : nullptr, t ? d_t : nullptr,
                                             normal ? d_normal : nullptr, front ? d_front : nullptr, uv ? d_uv : nullptr,
                                             point ? d_point : nullptr, (uint32_t*)c->d_overflow.p);
@@ -1140,7 +1185,7 @@ int rt_intersect_batch_noalloc(rt_ctx* c, uint64_t n, const float* ox, const flo
     unsigned char* const sc = c->noalloc_scratch;
     uint32_t* const flag = (uint32_t*)sc;
     const float* in[7] = {ox, oy, oz, dx, dy, dz, time};
-    const rtk::TraceCfg cfg{c->stack_entries, c->has_groups, false};
+    const rtk::TraceCfg cfg{c->stack_entries, c->has_groups, false, c->scene.nested != 0u};
     HIP_TRY(c, hipMemsetAsync(flag, 0, 4, c->stream));  // the array keeps the last call's contents
     if (is_device_ptr(ox)) {
         HIP_TRY(c, rtk::launch_intersect_batch(c->stream, cfg, c->scene, n, in, tmin, tmax, seed, prim, inst, t, normal, front, uv, point, flag));
@@ -1499,7 +1544,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 128, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
         const rtk::Queues q{(uint32_t*)c->d_counts.p, c->cap_shard};
-        const rtk::TraceCfg tcfg{c->stack_entries, c->has_groups, c->count_visits};
+        const rtk::TraceCfg tcfg{c->stack_entries, c->has_groups, c->count_visits, c->scene.nested != 0u};
         unsigned long long* d_stats = (unsigned long long*)c->d_rays.p;
         uint32_t* d_ovf = (uint32_t*)c->d_overflow.p;
         float4* d_rad = (float4*)c->d_radiance.p;

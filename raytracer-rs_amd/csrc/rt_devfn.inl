@@ -66,6 +66,20 @@ DEV f3 xf_vector(const float* m, f3 v) {
     return {(m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
             (m[8] * v.x + m[9] * v.y) + m[10] * v.z};
 }
+// The world ray (o, d) as instance g's own object sees it: TransformedObject::intersect (shapes.rs:66-70) of every
+// instance around g, outermost first, then of g itself -- the same products in the same order as the nested calls.
+DEV void instance_ray(const Scene& S, int g, f3& o, f3& d) {
+    const uint32_t depth = S.groups[g].depth;
+    for (uint32_t level = 0; level <= depth; level++) {
+        int a = g;
+        for (uint32_t k = depth - level; k > 0u; k--) a = S.groups[a].parent;
+        const Group& G = S.groups[a];
+        if (G.has_xform) {
+            o = xf_point(G.minv, o);
+            d = xf_vector(G.minv, d);
+        }
+    }
+}
 
 // ---- tables the shading kernels stage in LDS ------------------------------------------------------------
 // Shading looks its records up with a different index in every lane: hit primitive -> material -> texture ->
@@ -656,7 +670,7 @@ DEV void walk_inner(const Scene& S, Walk& w, float tmin, const Stack& stk, uint3
 }
 // One non-inner step: tests a leaf's primitives, enters an instance or leaves it, then takes the next entry
 // from the stack.  No-op when cur is an inner node or empty.
-template <int STRIDE, bool GROUPS, bool COUNT>
+template <int STRIDE, int GROUPS, bool COUNT>
 DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin, const Stack& stk, uint32_t* overflow_flag,
                    TraceCount* cnt) {
     const uint32_t type = w.cur >> 30;
@@ -677,7 +691,14 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
         w.cur = REF_EMPTY;
         if (root != REF_EMPTY) {
             if (w.sp < (int)S.stack_cap) {
-                if (G.has_xform) walk_set_ray(w, xf_point(G.minv, wo), xf_vector(G.minv, wd));  // shapes.rs:66-70
+                // shapes.rs:66-70; an instance inside an instance (kernels compiled with GROUPS == 2) is handed the ray
+                // of the one around it
+                if (G.has_xform) {
+                    if (GROUPS == 2 && w.grp >= 0)
+                        walk_set_ray(w, xf_point(G.minv, w.o), xf_vector(G.minv, w.d));
+                    else
+                        walk_set_ray(w, xf_point(G.minv, wo), xf_vector(G.minv, wd));
+                }
                 stack_put<STRIDE>(stk, w.sp, REF_SENTINEL);
                 w.sp++;
                 w.grp = (int)g;
@@ -686,9 +707,15 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
                 *overflow_flag = 1u;
             }
         }
-    } else {  // REF_SENTINEL: the instance's subtree is finished, back to the world ray
-        walk_set_ray(w, wo, wd);
-        w.grp = -1;
+    } else if (GROUPS) {  // REF_SENTINEL: the instance's subtree is finished, back to the ray of whatever is around it
+        int parent = -1;
+        f3 o = wo, d = wd;
+        if (GROUPS == 2) {
+            parent = S.groups[w.grp].parent;
+            if (parent >= 0) instance_ray(S, parent, o, d);
+        }
+        walk_set_ray(w, o, d);
+        w.grp = parent;
         w.cur = REF_EMPTY;
     }
     if (w.cur == REF_EMPTY && w.sp > 0) {  // next entry from the stack
@@ -743,11 +770,11 @@ DEV void trace_flat(const Scene& S, f3 wo, f3 wd, float time, float tmin, float 
 // are still descending do not drag the (long) primitive tests of the others along on every iteration.
 // FLAT: the scene is traced without a tree (Scene::flat); a template parameter, so that neither form carries the
 // registers of the other.
-template <int STRIDE, bool GROUPS, bool FLAT, bool COUNT = false>
+template <int STRIDE, int GROUPS, bool FLAT, bool COUNT = false>
 DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
                    uint32_t bounce, Hit& best, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
     if (FLAT) {
-        trace_flat<GROUPS, COUNT>(S, wo, wd, time, tmin, tmax, best, cnt);
+        trace_flat<GROUPS != 0, COUNT>(S, wo, wd, time, tmin, tmax, best, cnt);
         if (GROUPS) apply_media<COUNT>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
         return;
     }
@@ -787,14 +814,12 @@ DEV void make_record(const Scene& S, const LdsTables& L, f3 wo, f3 wd, float tim
         return;
     }
     f3 o = wo, d = wd;
-    const Group* G = nullptr;
     if (h.grp >= 0) {
-        G = S.groups + h.grp;
-        if (G->has_xform) {
-            o = xf_point(G->minv, wo);
-            d = xf_vector(G->minv, wd);
-        } else {
-            G = nullptr;
+        if (S.nested) {
+            instance_ray(S, h.grp, o, d);
+        } else if (S.groups[h.grp].has_xform) {
+            o = xf_point(S.groups[h.grp].minv, wo);
+            d = xf_vector(S.groups[h.grp].minv, wd);
         }
     }
     float4 A, B;
@@ -829,10 +854,16 @@ DEV void make_record(const Scene& S, const LdsTables& L, f3 wo, f3 wd, float tim
     }
     bool front = dot3(d, outward) < 0.0f;  // hit_record.rs:32-42
     f3 normal = front ? outward : -outward;
-    if (G) {  // shapes.rs:74-88: normal through M (not its inverse transpose), then face-set again
-        f3 nw = normalize3(xf_vector(G->m, normal));
-        point = xf_point(G->m, point);
-        front = dot3(wd, nw) < 0.0f;
+    // shapes.rs:74-88 at every instance around the primitive, innermost first: normal through M (not its inverse
+    // transpose), then face-set again against the ray that instance was handed
+    for (int a = h.grp; a >= 0; a = S.nested ? S.groups[a].parent : -1) {
+        const Group& G = S.groups[a];
+        if (!G.has_xform) continue;
+        f3 nw = normalize3(xf_vector(G.m, normal));
+        point = xf_point(G.m, point);
+        f3 lo = wo, ld = wd;
+        if (S.nested && G.parent >= 0) instance_ray(S, G.parent, lo, ld);
+        front = dot3(ld, nw) < 0.0f;
         normal = front ? nw : -nw;
     }
     rec.point = point;

@@ -77,8 +77,12 @@ struct alignas(16) Group {
     uint32_t order;     // instance: instance index; medium: medium index (RNG salt, reported id)
     uint32_t flat_range;  // the group's primitives as first | (count-1) << 26, FLAT_NONE when empty or more than 64
     float blo[3], bhi[3]; // widened box of the group's primitives in the group's own space (culls medium queries)
-    uint32_t pad[2];
+    // An instance may sit inside another instance (TransformedObject<T> takes any Hittable, shapes.rs:26-41): parent
+    // is the enclosing instance group or -1, depth the number of instances around this one (at most MAX_NESTING - 1).
+    int32_t parent;
+    uint32_t depth;
 };
+constexpr uint32_t MAX_NESTING = 4u;
 constexpr uint32_t FLAT_NONE = 0xFFFFFFFFu;
 static_assert(sizeof(Group) == 160, "Group must be 160 B");
 
@@ -140,6 +144,7 @@ struct Scene {
     // lds_scene != 0: the scene is small enough that the shading kernels also keep the primitive, material and
     // texture records in LDS (n_prims, n_mats, n_texs records of 32 bytes each)
     uint32_t lds_scene, n_mats, n_texs;
+    uint32_t nested;  // != 0: some instance stands inside another one (Group::parent >= 0 somewhere)
 };
 
 }  // namespace rtd

@@ -52,6 +52,7 @@ struct TraceCfg {
     int stack_entries;  // per-lane traversal stack in LDS (Scene::stack_cap)
     bool has_groups;    // scene holds instances / media
     bool count_visits;  // instrumented traversal (node / primitive counters)
+    bool nested = false;  // some instance stands inside another one (Scene::nested): kernels compiled for that walk
 };
 
 // stats: 64-bit words: [0] += rays traced by the per-bounce kernels; with count_visits also [1] += inner nodes

@@ -225,7 +225,7 @@ DEV uint32_t primary_count(uint32_t n, uint32_t s) {
 
 // Held to 128 VGPRs (4 waves per SIMD): one more resident wave than the compiler's own choice hides more of
 // the queue loads and the compaction barrier than the few spilled values cost.
-template <bool GROUPS, bool COUNT, bool PRIMARY, bool FLAT>
+template <int GROUPS, bool COUNT, bool PRIMARY, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : BOUNCE_WAVES))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
                                                         rtk::PathState out, rtk::Queues q, uint32_t bounce,
                                                         float4* __restrict__ radiance, unsigned long long* stats,
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 7
 #endif
-template <bool GROUPS, bool COUNT, bool FLAT>
+template <int GROUPS, bool COUNT, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES))) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
                                                        uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS, uint32_t lds_entries,
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
             const uint32_t at = shard_base + i;
             const float4 ot = in.o_time[at], ds = in.d_slot[at];
             Hit h;
-            trace_flat<GROUPS, COUNT>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, h, &tc);
+            trace_flat<GROUPS != 0, COUNT>(S, mk3(ot.x, ot.y, ot.z), mk3(ds.x, ds.y, ds.z), ot.w, 0.005f, INF_F, h, &tc);
             hits[at] = make_float4(h.t, __uint_as_float(h.prim), __int_as_float(h.grp), __uint_as_float(h.key));
         }
         if (COUNT) {
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
                     const f3 ld = mk3(world_ray[3 * rtk::BLOCK], world_ray[4 * rtk::BLOCK], world_ray[5 * rtk::BLOCK]);
                     walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, lo, ld, time, 0.005f, stk, overflow_flag, &tc);
                 } else {
-                    walk_leaf<rtk::BLOCK, false, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
+                    walk_leaf<rtk::BLOCK, 0, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
                 }
             } else {
                 walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 // read-back of the queue lengths) rather than work, so the remaining paths are finished here in one go:
 // each lane takes one queued path and runs the ray_color loop (main.rs:44-63) to its end.  A path's draws
 // are keyed by (stream, bounce), so the result is the one the bounce-per-launch kernels would have produced.
-template <bool GROUPS, bool FLAT>
+template <int GROUPS, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::Queues q,
                                                         uint32_t bounce, float4* __restrict__ radiance,
                                                         unsigned long long* stats, uint32_t* overflow_flag) {
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
 // no launch per bounce.  That only pays where every lane of a wave does the same work per bounce -- scenes traced
 // flat; through a tree the lanes' walks diverge and the queue-based kernels, which re-pack rays between the walk
 // and the shading, stay ahead.  Draws are keyed by (stream, bounce): the image is the one the other pipelines give.
-template <bool GROUPS, bool FLAT>
+template <int GROUPS, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : PATHS_WAVES))) void k_paths(
     Scene S, rtk::RenderConst rc, rtk::Batch batch, float4* __restrict__ radiance, unsigned long long* stats,
     uint32_t* overflow_flag, uint32_t REGEN) {
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_resolve(const float* __restrict_
     }
 }
 
-template <bool GROUPS, bool FLAT>
+template <int GROUPS, bool FLAT>
 __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigned long long n, const float* __restrict__ ox,
                                                                  const float* __restrict__ oy, const float* __restrict__ oz,
                                                                  const float* __restrict__ dx, const float* __restrict__ dy,
@@ -665,7 +665,11 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
             }
             prim[i] = id;
         }
-        if (inst) inst[i] = (hit && h.grp >= 0) ? (int32_t)S.groups[h.grp].order : -1;
+        if (inst) {  // the instance the record came out of last: the outermost one around the primitive (shapes.rs:74-88)
+            int g = hit ? h.grp : -1;
+            while (g >= 0 && S.groups[g].parent >= 0) g = S.groups[g].parent;
+            inst[i] = g >= 0 ? (int32_t)S.groups[g].order : -1;
+        }
         if (t) t[i] = hit ? h.t : INF_F;
         if (normal) {
             normal[3 * i] = rec.normal.x;
@@ -747,21 +751,26 @@ inline int grid_sharded(uint32_t blocks_per_shard, const void* fn, int oversub, 
 namespace rtk {
 
 // groups x instrumented -> template instance
-#define RT_DISPATCH_GC(cfg, CALL, F)                       \
-    do {                                                   \
-        if ((cfg).has_groups) {                            \
-            if ((cfg).count_visits) CALL(true, true, F);   \
-            else CALL(true, false, F);                     \
-        } else {                                           \
-            if ((cfg).count_visits) CALL(false, true, F);  \
-            else CALL(false, false, F);                    \
-        }                                                  \
+// (the first template argument: 0 no groups, 1 instances / media, 2 instances inside instances as well)
+#define RT_DISPATCH_GC(cfg, CALL, F)                   \
+    do {                                               \
+        if ((cfg).has_groups) {                        \
+            if ((cfg).count_visits) CALL(1, true, F);  \
+            else CALL(1, false, F);                    \
+        } else {                                       \
+            if ((cfg).count_visits) CALL(0, true, F);  \
+            else CALL(0, false, F);                    \
+        }                                              \
     } while (0)
 // groups x instrumented x traced-without-a-tree -> template instance
-#define RT_DISPATCH_TRACE_CFG(cfg, flat, CALL)        \
-    do {                                              \
-        if (flat) RT_DISPATCH_GC(cfg, CALL, true);    \
-        else RT_DISPATCH_GC(cfg, CALL, false);        \
+// (a scene with nested instances always takes the tree)
+#define RT_DISPATCH_TRACE_CFG(cfg, flat, CALL)             \
+    do {                                                   \
+        if (flat) RT_DISPATCH_GC(cfg, CALL, true);         \
+        else if ((cfg).nested) {                           \
+            if ((cfg).count_visits) CALL(2, true, false);  \
+            else CALL(2, false, false);                    \
+        } else RT_DISPATCH_GC(cfg, CALL, false);           \
     } while (0)
 
 // LDS bytes of the per-lane traversal stacks of one block
@@ -858,12 +867,14 @@ hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
     if (blocks_per_shard > (uint32_t)MAX_BLOCKS_PER_SHARD) blocks_per_shard = MAX_BLOCKS_PER_SHARD;
     const dim3 grid(blocks_per_shard * NSHARD), block(BLOCK);
 #define RT_FINISH(G, F) hipLaunchKernelGGL((k_finish<G, F>), grid, block, smem, s, scene, rc, in, q, bounce, radiance, stats, overflow_flag)
-    if (cfg.has_groups) {
-        if (scene.flat) RT_FINISH(true, true);
-        else RT_FINISH(true, false);
+    if (cfg.nested) {
+        RT_FINISH(2, false);
+    } else if (cfg.has_groups) {
+        if (scene.flat) RT_FINISH(1, true);
+        else RT_FINISH(1, false);
     } else {
-        if (scene.flat) RT_FINISH(false, true);
-        else RT_FINISH(false, false);
+        if (scene.flat) RT_FINISH(0, true);
+        else RT_FINISH(0, false);
     }
 #undef RT_FINISH
     return hipGetLastError();
@@ -888,12 +899,14 @@ hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
         const dim3 grid((uint32_t)std::max<unsigned long long>(1, std::min(all, std::min(std::max({want, fit, small}), 1ull << 20)))); \
         hipLaunchKernelGGL((k_paths<G, F>), grid, dim3(BLOCK), smem, s, scene, rc, batch, radiance, stats, overflow_flag, regen); \
     } while (0)
-    if (cfg.has_groups) {
-        if (scene.flat) RT_PATHS(true, true);
-        else RT_PATHS(true, false);
+    if (cfg.nested) {
+        RT_PATHS(2, false);
+    } else if (cfg.has_groups) {
+        if (scene.flat) RT_PATHS(1, true);
+        else RT_PATHS(1, false);
     } else {
-        if (scene.flat) RT_PATHS(false, true);
-        else RT_PATHS(false, false);
+        if (scene.flat) RT_PATHS(0, true);
+        else RT_PATHS(0, false);
     }
 #undef RT_PATHS
     return hipGetLastError();

@@ -132,6 +132,34 @@ Scene cornell_smoke() {  // main.rs:207-238
     return s;
 }
 
+// Not a reference preset: the Cornell shell around transformed objects INSIDE transformed objects, which the
+// reference's types allow (TransformedObject<T: Hittable>, shapes.rs:26-41) and none of its scenes uses.  One block is
+// a translation around a rotation around a box; the other stacks four transforms (translate, rotate, a BVH of three
+// objects, two of them transformed again, one of those twice).
+Scene nested_instances() {
+    Scene s = Scene::new_();
+    cornell_shell(s, Vec3A(15.0f, 15.0f, 15.0f), Vec2(213.0f, 227.0f), Vec2(343.0f, 332.0f));
+    Vec3A white(0.73f, 0.73f, 0.73f);
+    {
+        auto turned = TransformedObject<Box2>::new_(Box2::new_(165.0f, 165.0f, 165.0f, LambertianMat::from_color(white)),
+                                                    Mat4::from_rotation_y(degree_to_rad(-18.0f)));
+        s.add_shape(TransformedObject<TransformedObject<Box2>>::new_(turned, Mat4::from_translation(Vec3(130.0f, 0.0f, 65.0f))));
+    }
+    Scene inner = Scene::new_();
+    inner.add_shape(Sphere::new_(Vec3A(60.0f, 200.0f, 60.0f), 40.0f, MetalMat::new_(Vec3A(0.8f, 0.85f, 0.88f), 0.0f)));
+    {
+        auto turned = TransformedObject<Box2>::new_(Box2::new_(80.0f, 80.0f, 80.0f, LambertianMat::from_color(Vec3A(0.65f, 0.05f, 0.05f))),
+                                                    Mat4::from_rotation_y(degree_to_rad(30.0f)));
+        inner.add_shape(TransformedObject<TransformedObject<Box2>>::new_(turned, Mat4::from_translation(Vec3(20.0f, 120.0f, 20.0f))));
+    }
+    inner.add_shape(TransformedObject<Sphere>::new_(Sphere::new_(Vec3A(0.0f, 0.0f, 0.0f), 30.0f, DielectricMat::new_(1.5f)),
+                                                    Mat4::from_translation(Vec3(120.0f, 60.0f, 100.0f))));
+    inner.add_shape(Box2::new_(165.0f, 100.0f, 165.0f, LambertianMat::from_color(white)));
+    auto turned = TransformedObject<BVHNode>::new_(BVHNode::from_scene(inner, 0.0f, 1.0f), Mat4::from_rotation_y(degree_to_rad(15.0f)));
+    s.add_shape(TransformedObject<TransformedObject<BVHNode>>::new_(turned, Mat4::from_translation(Vec3(265.0f, 0.0f, 295.0f))));
+    return s;
+}
+
 Scene final_scene() {  // main.rs:240-305
     Scene s = Scene::new_();
     Scene boxes = Scene::new_();
@@ -246,8 +274,8 @@ void* rth_scene_build(const char* name, uint32_t seed, const char* earthmap_path
             p.origin = Vec3A(26.0f, 3.0f, 6.0f);
             p.target = Vec3A(0.0f, 2.0f, 0.0f);
             p.background = Vec3A::ZERO();
-        } else if (n == "cornell_box" || n == "cornell_smoke") {
-            b->world = n == "cornell_box" ? cornell_box() : cornell_smoke();
+        } else if (n == "cornell_box" || n == "cornell_smoke" || n == "nested_instances") {
+            b->world = n == "cornell_box" ? cornell_box() : (n == "cornell_smoke" ? cornell_smoke() : nested_instances());
             p.origin = Vec3A(278.0f, 278.0f, -800.0f);
             p.target = Vec3A(278.0f, 278.0f, 0.0f);
             p.fov_deg = 40.0f;

@@ -574,10 +574,19 @@ struct TransformedObject : Hittable {
         return true;
     }
     void flatten(FlatScene& fs, uint32_t group) const override {
-        if (group != 0) throw std::runtime_error("TransformedObject nested inside another group is not supported on the device");
+        // inside another TransformedObject: an instance group whose parent is that one (at most four stacked);
+        // inside a medium's boundary (beyond the one transform the medium takes over itself): not on the device
+        uint32_t depth = 0;
+        for (uint32_t a = group; a != 0; a = fs.groups[a - 1].parent) {
+            if (fs.groups[a - 1].kind != RT_GROUP_INSTANCE)
+                throw std::runtime_error("TransformedObject nested inside a ConstantMedium boundary is not supported on the device");
+            depth++;
+        }
+        if (depth >= 4) throw std::runtime_error("TransformedObject nested more than 4 deep is not supported on the device");
         rt_group g{};
         g.kind = RT_GROUP_INSTANCE;
         g.has_xform = 1;
+        g.parent = group;
         transform.to_rows(g.m);
         inv_transform.to_rows(g.minv);
         fs.groups.push_back(g);

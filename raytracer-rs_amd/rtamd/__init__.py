@@ -20,7 +20,7 @@ LIB_DIR = Path(__import__("os").environ.get("RTAMD_LIB_DIR", PKG_DIR / "lib"))
 EARTHMAP = REPO_ROOT / "tests" / "golden" / "earthmap.ppm"
 
 SCENES = ("random_world", "two_spheres", "two_perlin_spheres", "earth", "simple_light", "cornell_box",
-          "cornell_smoke", "final_scene", "synth_spheres")
+          "cornell_smoke", "final_scene", "nested_instances", "synth_spheres")
 
 RT_OK = 0
 STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPPORTED", -4: "RT_ERR_NOT_COMMITTED",
@@ -93,7 +93,7 @@ class rt_texture(C.Structure):
 
 class rt_group(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("has_xform", C.c_uint32), ("m", C.c_float * 12), ("minv", C.c_float * 12),
-                ("neg_inv_density", C.c_double), ("mat", C.c_uint32), ("reserved", C.c_uint32)]
+                ("neg_inv_density", C.c_double), ("mat", C.c_uint32), ("parent", C.c_uint32)]
 
 
 _core = None

@@ -1,7 +1,7 @@
 // Host-logic check (no GPU) of what the C++ mirror of the reference's scene API accepts: the reference lets
-// TransformedObject<T> and ConstantMedium<T> wrap any Hittable (shapes.rs:26-41, 624-646); the device takes ONE level
-// of transform and media at the top level.  Anything deeper must be refused with a message that says so -- never
-// flattened into something else.
+// TransformedObject<T> and ConstantMedium<T> wrap any Hittable (shapes.rs:26-41, 624-646); the device takes up to four
+// transforms stacked inside each other, and media at the top level whose boundary carries at most one transform.
+// Anything else must be refused with a message that says so -- never flattened into something else.
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -37,10 +37,31 @@ int main() {
             ok = false;
         }
     }
-    ok &= refuses("transform inside transform", [&](FlatScene& fs) {
+    {  // transform inside transform: two instance groups, the inner one names the outer one as its parent
+        FlatScene fs;
         auto inner = TransformedObject<Sphere>::new_(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), turn);
         TransformedObject<TransformedObject<Sphere>>::new_(inner, shift).flatten(fs, 0);
-    }, "nested");
+        if (fs.groups.size() != 2 || fs.groups[0].parent != 0 || fs.groups[1].parent != 1 || fs.sph_group.size() != 1 || fs.sph_group[0] != 2) {
+            std::printf("FAIL two levels\n");
+            ok = false;
+        }
+    }
+    {  // four stacked transforms are taken, five are refused
+        using T1 = TransformedObject<Sphere>;
+        using T2 = TransformedObject<T1>;
+        using T3 = TransformedObject<T2>;
+        using T4 = TransformedObject<T3>;
+        using T5 = TransformedObject<T4>;
+        auto t1 = T1::new_(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), turn);
+        auto t4 = T4::new_(T3::new_(T2::new_(t1, shift), turn), shift);
+        FlatScene fs;
+        t4.flatten(fs, 0);
+        if (fs.groups.size() != 4 || fs.groups[3].parent != 3) {
+            std::printf("FAIL four levels\n");
+            ok = false;
+        }
+        ok &= refuses("five stacked transforms", [&](FlatScene& f5) { T5::new_(t4, turn).flatten(f5, 0); }, "more than 4 deep");
+    }
     ok &= refuses("medium inside transform", [&](FlatScene& fs) {
         auto fog = ConstantMedium<Sphere>::from_color(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), 0.1f, Vec3A(1, 1, 1));
         TransformedObject<ConstantMedium<Sphere>>::new_(fog, shift).flatten(fs, 0);

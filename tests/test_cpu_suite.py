@@ -189,9 +189,10 @@ def test_bvh_builder_invariants(bvh_check, n, seed, leaf):
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), r.stdout[-500:]
 
 
-def test_nesting_beyond_one_level_is_refused_with_a_message(tmp_path):
+def test_nesting_the_device_does_not_take_is_refused_with_a_message(tmp_path):
     """TransformedObject<T> / ConstantMedium<T> take any Hittable in the reference (shapes.rs:26-41, 624-646); the device
-    takes one transform level and top-level media.  The mirror API must refuse deeper nesting, naming the reason."""
+    takes up to four stacked transforms and top-level media.  The mirror API must flatten the former into parent-linked
+    groups and refuse anything else, naming the reason."""
     exe = tmp_path / "nesting_check"
     subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), str(ROOT / "tests" / "cpp" / "nesting_check.cpp")], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)

@@ -125,6 +125,46 @@ def test_kat_instance_and_medium(gpu_ctx):
     assert (r["prim"] == -2).sum() > 40
 
 
+def test_kat_instance_inside_instance(gpu_ctx):
+    """TransformedObject<TransformedObject<Sphere>> through the raw ABI (shapes.rs:26-41 takes any Hittable): the
+    outer group shifts x by 10, the inner one (parent = outer) shifts y by 3, the unit sphere sits at the origin of
+    the inner space, i.e. at (10, 3, 0) in the world.  Power-of-two-free but exact arithmetic: every value below is
+    representable, so the answers are exact."""
+    mats, texs = solid_lambertian()
+    outer = rtamd.rt_group(kind=1, has_xform=1)
+    outer.m = (C.c_float * 12)(1, 0, 0, 10, 0, 1, 0, 0, 0, 0, 1, 0)
+    outer.minv = (C.c_float * 12)(1, 0, 0, -10, 0, 1, 0, 0, 0, 0, 1, 0)
+    inner = rtamd.rt_group(kind=1, has_xform=1, parent=1)
+    inner.m = (C.c_float * 12)(1, 0, 0, 0, 0, 1, 0, 3, 0, 0, 1, 0)
+    inner.minv = (C.c_float * 12)(1, 0, 0, 0, 0, 1, 0, -3, 0, 0, 1, 0)
+    # a second sphere directly in the outer group, and one in the world, so that the walk has to come back out
+    spheres = dict(c0r=[[0, 0, 0, 1], [0, -4, 0, 1], [0, 0, 20, 1]], mat=[0, 0, 0], id=[0, 1, 2], group=[2, 1, 0])
+    info = gpu_ctx.set_scene(spheres=spheres, groups=[outer, inner], materials=mats, textures=texs)
+    assert info["n_groups"] == 2
+    r = gpu_ctx.intersect(one_ray((10, 3, -5), (0, 0, 1)))
+    assert r["prim"][0] == 0 and r["inst"][0] == 0 and r["t"][0] == 4.0 and r["point"][0].tolist() == [10.0, 3.0, -1.0]
+    assert r["front"][0] == 1 and r["normal"][0].tolist() == [0.0, 0.0, -1.0]
+    r = gpu_ctx.intersect(one_ray((10, -4, -5), (0, 0, 1)))  # the sphere of the outer group alone
+    assert r["prim"][0] == 1 and r["inst"][0] == 0 and r["t"][0] == 4.0 and r["point"][0].tolist() == [10.0, -4.0, -1.0]
+    r = gpu_ctx.intersect(one_ray((0, 0, -5), (0, 0, 1)))  # misses both instances' boxes, hits the world sphere
+    assert r["prim"][0] == 2 and r["inst"][0] == -1 and r["t"][0] == 24.0
+    r = gpu_ctx.intersect(one_ray((10, 3, 5), (0, 0, 1)))  # through nothing but the world (starts behind the instance)
+    assert r["prim"][0] == -1
+    # a ray that enters the outer box, the inner box, misses the inner sphere, leaves both and hits the world sphere:
+    # it passes (10.9, 3.9, 0), a corner region of the inner box 1.27 away from the sphere's centre, on its way to (0, 0, 20)
+    o, tgt = np.array([13.625, 4.875, -5.0]), np.array([0.0, 0.0, 20.0])
+    r = gpu_ctx.intersect(one_ray(tuple(o), tuple(tgt - o)))
+    assert r["prim"][0] == 2 and r["inst"][0] == -1
+    cam = rtamd.camera_new((10, 0, -12), (10, 0, 0), (0, 1, 0), 1.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    imgs = []
+    for pipe in (0, 1, 2):
+        gpu_ctx.set_pipeline(pipe)
+        img, st = gpu_ctx.render(32, 32, cam, 8, background=(1.0, 1.0, 1.0))
+        imgs.append(img)
+    gpu_ctx.set_pipeline(-1)
+    assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2]) and imgs[0].min() < 8.0 * 0.9
+
+
 def test_empty_medium_group_is_never_hit(gpu_ctx):
     """A ConstantMedium whose boundary holds no primitive (group 1) next to a normal one (group 2): the empty one
     must not be evaluated -- it has no record in the device's media list -- and the other keeps medium index 1,
@@ -211,6 +251,23 @@ def test_error_paths(gpu_ctx):
     assert e.value.code == -3 and "16" in str(e.value)
     with pytest.raises(rtamd.RtError):
         ctx.intersect(one_ray((0, 0, 0), (0, 0, 1)))  # the failed commit left no scene behind
+    # groups inside groups (rt_group.parent): instances up to four deep; anything else is refused by name
+    one = dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0], group=[1])
+    inst = lambda parent=0: rtamd.rt_group(kind=1, has_xform=0, parent=parent)
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.set_scene(spheres=one, groups=[inst(2), inst()], materials=mats, textures=texs)  # parent after child
+    assert e.value.code == -1 and "parent" in str(e.value)
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.set_scene(spheres=one, groups=[inst(), rtamd.rt_group(kind=2, neg_inv_density=-1.0, mat=0, parent=1)], materials=mats, textures=texs)
+    assert e.value.code == -3 and "medium" in str(e.value)
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.set_scene(spheres=one, groups=[rtamd.rt_group(kind=2, neg_inv_density=-1.0, mat=0), inst(1)], materials=mats, textures=texs)
+    assert e.value.code == -3 and "medium" in str(e.value)
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.set_scene(spheres=one, groups=[inst(), inst(1), inst(2), inst(3), inst(4)], materials=mats, textures=texs)
+    assert e.value.code == -3 and "4 deep" in str(e.value)
+    ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0], group=[4]), groups=[inst(), inst(1), inst(2), inst(3)], materials=mats, textures=texs)
+    assert ctx.intersect(one_ray((0, 0, -5), (0, 0, 1)))["t"][0] == 4.0
     ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0]), materials=mats, textures=texs)
     img, st = ctx.render(8, 8, cam, 2, depth=253)
     assert st["rays"] >= 128 and np.isfinite(img).all()
@@ -248,7 +305,7 @@ def test_golden_images(gpu_ctx, name):
 # ---- image parity with the oracle at equal spp -------------------------------------------------------
 @pytest.mark.parametrize("name,aspect", [("random_world", 16 / 9), ("two_spheres", 16 / 9), ("two_perlin_spheres", 16 / 9),
                                          ("earth", 16 / 9), ("simple_light", 16 / 9), ("cornell_box", 1.0),
-                                         ("cornell_smoke", 1.0), ("final_scene", 1.0)])
+                                         ("cornell_smoke", 1.0), ("final_scene", 1.0), ("nested_instances", 1.0)])
 def test_image_matches_oracle_at_equal_spp(gpu_ctx, name, aspect):
     w, spp = 160, 8
     h = rtamd.image_height(w, aspect)
@@ -342,7 +399,8 @@ def test_rank_split_sample_split_and_batch_size_change_no_bit(gpu_ctx):
     small.close()
 
 
-@pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "two_perlin_spheres", "earth", "cornell_box"])
+@pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "two_perlin_spheres", "earth", "cornell_box",
+                                  "nested_instances"])
 def test_fused_and_split_pipelines_give_the_same_bits(name):
     w, h, spp = 150, 100, 5
     ctx = rtamd.Context(0)
@@ -416,7 +474,7 @@ def test_contexts_render_concurrently_from_host_threads():
         ctx.close()
 
 
-@pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "earth"])
+@pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "earth", "nested_instances"])
 def test_tail_kernel_changes_no_bit(name):
     """The last live paths of a batch are walked to their end by one launch (k_finish) instead of one launch per
     bounce.  Where the hand-over happens must not matter: never, after the first bounce, or somewhere in between."""
