@@ -22,7 +22,8 @@ struct Workspace {
     size_t sort_tmp_bytes = 0;
     uint32_t* parent_inner = nullptr;     // n-1 entries: parent node | child slot << 31
     uint32_t* parent_leaf = nullptr;      // n entries
-    uint32_t* arrived = nullptr;          // n-1 counters of the bottom-up pass
+    void* leaf_boxes = nullptr;           // n boxes (two float4 each) of the sorted primitives
+    void* box_table = nullptr;            // unions of aligned blocks of 64 leaves and a sparse table over the blocks
     uint32_t* scalars = nullptr;          // 12 ordered-int bounds words + depth word
     uint32_t n = 0;
     void release();

@@ -4,8 +4,10 @@
 //   k_morton     63-bit Morton code of the box centre (21 bits per axis) + primitive index
 //   (rocPRIM)    radix sort of (code, index)
 //   k_gather     primitive records into sorted order (leaf i = sorted primitive i)
-//   k_hierarchy  one thread per inner node: its key range and split by binary search on common prefixes
-//   k_fit        one thread per leaf: climbs to the root; the second thread to arrive at a node carries on
+//   k_leaf_boxes, k_block_boxes, k_table_level   the leaves' boxes and a range structure over them: the union of every
+//                aligned block of 64 leaves and, over those blocks, a sparse table (level k: runs of 2^k blocks)
+//   k_hierarchy  one thread per inner node: its key range and split by binary search on common prefixes; a node
+//                covers a contiguous run of sorted leaves, so the boxes of its two children are two range queries
 //   k_depth      one thread per leaf: inner nodes on its path to the root -> atomic max
 //   k_widen      one thread per inner node: the four-child form of the finished tree (any builder's)
 //
@@ -176,9 +178,77 @@ __device__ int prefix(const unsigned long long* keys, int n, int i, int j) {
     return __clzll((long long)(a ^ b));
 }
 
+// ---- boxes by range query -----------------------------------------------------------------------------------
+// Every inner node of the radix tree covers a contiguous run [first, last] of the sorted leaves, and min / max are exact
+// and associative: a child's box is the union of the leaf boxes of its run, whichever way the union is bracketed.  So
+// nothing has to climb the tree (one thread per leaf meeting its sibling at every level costs two device-wide fences
+// per node: 80 ms for 10 M leaves); a node reads its boxes from a structure made in three streaming passes: the leaf
+// boxes, the union of each aligned block of FIT_BLOCK leaves, and a sparse table over the blocks.  A run shorter than
+// two blocks is read leaf by leaf, a longer one as two partial blocks plus two table entries.
+constexpr uint32_t FIT_BLOCK = 64;
+
+__device__ Box3 load_box(const float4* boxes, uint32_t i) {
+    const float4 lo = boxes[2u * i], hi = boxes[2u * i + 1u];
+    return Box3{{lo.x, lo.y, lo.z}, {hi.x, hi.y, hi.z}};
+}
+__device__ void merge_box(Box3& b, const float4* boxes, uint32_t i) {
+    const float4 lo = boxes[2u * i], hi = boxes[2u * i + 1u];
+    b.lo[0] = fminf(b.lo[0], lo.x);
+    b.lo[1] = fminf(b.lo[1], lo.y);
+    b.lo[2] = fminf(b.lo[2], lo.z);
+    b.hi[0] = fmaxf(b.hi[0], hi.x);
+    b.hi[1] = fmaxf(b.hi[1], hi.y);
+    b.hi[2] = fmaxf(b.hi[2], hi.z);
+}
+__device__ void store_box(float4* boxes, uint32_t i, const Box3& b) {
+    boxes[2u * i] = make_float4(b.lo[0], b.lo[1], b.lo[2], 0.0f);
+    boxes[2u * i + 1u] = make_float4(b.hi[0], b.hi[1], b.hi[2], 0.0f);
+}
+__global__ __launch_bounds__(BLOCK) void k_leaf_boxes(const rtd::Prim* sorted, const rtd::Moving* moving, uint32_t n, float t0, float t1,
+                                                       float4* leaf) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) store_box(leaf, i, prim_box(sorted[i], moving, t0, t1));
+}
+// level 0 of the table: block b = leaves [b * FIT_BLOCK, (b + 1) * FIT_BLOCK) (the last block may be short)
+__global__ __launch_bounds__(BLOCK) void k_block_boxes(const float4* leaf, uint32_t n, uint32_t nb, float4* table) {
+    const uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= nb) return;
+    const uint32_t first = b * FIT_BLOCK, end = min(n, first + FIT_BLOCK);
+    Box3 box = load_box(leaf, first);
+    for (uint32_t i = first + 1u; i < end; i++) merge_box(box, leaf, i);
+    store_box(table, b, box);
+}
+// level k (runs of 2^k blocks starting at b) from level k - 1
+__global__ __launch_bounds__(BLOCK) void k_table_level(float4* table, uint32_t nb, uint32_t k) {
+    const uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t half = 1u << (k - 1u);
+    if (b + 2u * half > nb) return;
+    const float4* below = table + 2ull * (k - 1u) * nb;
+    Box3 box = load_box(below, b);
+    merge_box(box, below, b + half);
+    store_box(table + 2ull * k * nb, b, box);
+}
+// union of the boxes of leaves l .. r (inclusive)
+__device__ Box3 range_box(const float4* leaf, const float4* table, uint32_t nb, uint32_t l, uint32_t r) {
+    Box3 b = load_box(leaf, l);
+    if (r - l < 2u * FIT_BLOCK) {
+        for (uint32_t i = l + 1u; i <= r; i++) merge_box(b, leaf, i);
+        return b;
+    }
+    // r - l >= 2 * FIT_BLOCK: at least one whole block lies strictly between the blocks of l and r
+    const uint32_t bl = l / FIT_BLOCK + 1u, br = r / FIT_BLOCK - 1u;
+    for (uint32_t i = l + 1u; i < bl * FIT_BLOCK; i++) merge_box(b, leaf, i);
+    for (uint32_t i = (br + 1u) * FIT_BLOCK; i <= r; i++) merge_box(b, leaf, i);
+    const uint32_t k = 31u - (uint32_t)__clz((int)(br - bl + 1u));
+    merge_box(b, table + 2ull * k * nb, bl);
+    merge_box(b, table + 2ull * k * nb, br + 1u - (1u << k));
+    return b;
+}
+
 // Radix tree over the sorted keys: inner node i covers a key range one of whose ends is i.
 __global__ __launch_bounds__(BLOCK) void k_hierarchy(const unsigned long long* keys, uint32_t n, uint32_t prim_base, uint32_t node_base,
-                                                      rtd::Node* nodes, uint32_t* parent_inner, uint32_t* parent_leaf) {
+                                                      rtd::Node* nodes, uint32_t* parent_inner, uint32_t* parent_leaf, const float4* leaf,
+                                                      const float4* table, uint32_t nb) {
     const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
     const int nn = (int)n;
     if (i >= nn - 1) return;
@@ -212,45 +282,13 @@ __global__ __launch_bounds__(BLOCK) void k_hierarchy(const unsigned long long* k
         parent_leaf[split + 1] = (uint32_t)i | SIDE_BIT;
     else
         parent_inner[split + 1] = (uint32_t)i | SIDE_BIT;
-}
-
-__device__ void store_child_box(rtd::Node* nd, uint32_t side, const Box3& b) {
-    float* lo = side ? nd->lo1 : nd->lo0;
-    float* hi = side ? nd->hi1 : nd->hi0;
+    const Box3 b0 = range_box(leaf, table, nb, (uint32_t)first, (uint32_t)split);
+    const Box3 b1 = range_box(leaf, table, nb, (uint32_t)split + 1u, (uint32_t)last);
     for (int k = 0; k < 3; k++) {
-        lo[k] = b.lo[k];
-        hi[k] = b.hi[k];
-    }
-}
-__device__ float load_coherent(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// Bottom-up fit.  A node stores the boxes of BOTH children, so a thread coming up from a child writes that
-// child's box into the parent, publishes it (fence + counter) and stops if it is the first to arrive; the
-// second reads the sibling's box, and their union is what it carries to the next level.
-__global__ __launch_bounds__(BLOCK) void k_fit(const rtd::Prim* sorted, const rtd::Moving* moving, uint32_t n, float t0, float t1,
-                                                rtd::Node* nodes, const uint32_t* parent_inner, const uint32_t* parent_leaf,
-                                                uint32_t* arrived) {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Box3 b = prim_box(sorted[i], moving, t0, t1);
-    uint32_t p = parent_leaf[i];
-    for (int level = 0; level < MAX_LEVELS; level++) {  // (a radix tree over 64+32 key bits is never deeper)
-        const uint32_t side = p >> 31, pi = p & ~SIDE_BIT;
-        rtd::Node* nd = nodes + pi;
-        store_child_box(nd, side, b);
-        __threadfence();
-        if (atomicAdd(&arrived[pi], 1u) == 0u) return;
-        __threadfence();
-        const float* slo = side ? nd->lo0 : nd->lo1;
-        const float* shi = side ? nd->hi0 : nd->hi1;
-        for (int k = 0; k < 3; k++) {
-            b.lo[k] = fminf(b.lo[k], load_coherent(slo + k));
-            b.hi[k] = fmaxf(b.hi[k], load_coherent(shi + k));
-        }
-        if (pi == 0u) return;  // the root has no parent
-        p = parent_inner[pi];
+        nd.lo0[k] = b0.lo[k];
+        nd.hi0[k] = b0.hi[k];
+        nd.lo1[k] = b1.lo[k];
+        nd.hi1[k] = b1.hi[k];
     }
 }
 
@@ -313,7 +351,7 @@ inline int grid_for(uint64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 }  // namespace
 
 void Workspace::release() {
-    void* all[] = {keys[0], keys[1], vals[0], vals[1], sort_tmp, parent_inner, parent_leaf, arrived, scalars};
+    void* all[] = {keys[0], keys[1], vals[0], vals[1], sort_tmp, parent_inner, parent_leaf, leaf_boxes, box_table, scalars};
     for (void* p : all)
         if (p) (void)hipFree(p);
     *this = Workspace();
@@ -336,7 +374,6 @@ hipError_t sort_world(hipStream_t s, Workspace& w, const rtd::Prim* unsorted, co
     }
     RTL_TRY(dev_alloc((void**)&w.parent_inner, (size_t)n * sizeof(uint32_t)));
     RTL_TRY(dev_alloc((void**)&w.parent_leaf, (size_t)n * sizeof(uint32_t)));
-    RTL_TRY(dev_alloc((void**)&w.arrived, (size_t)n * sizeof(uint32_t)));
     RTL_TRY(dev_alloc((void**)&w.scalars, 16 * sizeof(uint32_t)));
     uint32_t init[16];
     for (int k = 0; k < 12; k++) init[k] = (k % 6) < 3 ? 0xFFFFFFFFu : 0u;
@@ -375,12 +412,24 @@ hipError_t build_tree(hipStream_t s, Workspace& w, const rtd::Prim* sorted, cons
                       uint32_t* depth) {
     if (n < 2 || w.n != n || !w.keys[1]) return hipErrorInvalidValue;
     const auto* keys = (const unsigned long long*)w.keys[1];  // sorted
-    RTL_TRY(hipMemsetAsync(w.arrived, 0, (size_t)n * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_hierarchy, dim3(grid_for(n - 1)), dim3(BLOCK), 0, s, keys, n, prim_base, node_base, nodes, w.parent_inner,
-                       w.parent_leaf);
+    // range structure over the leaf boxes (see range_box)
+    const uint32_t nb = (n + FIT_BLOCK - 1u) / FIT_BLOCK;
+    uint32_t levels = 1;
+    while ((2u << (levels - 1u)) <= nb) levels++;
+    if (!w.leaf_boxes) RTL_TRY(dev_alloc((void**)&w.leaf_boxes, 2ull * n * sizeof(float4)));
+    if (!w.box_table) RTL_TRY(dev_alloc((void**)&w.box_table, 2ull * levels * nb * sizeof(float4)));
+    float4* leaf = (float4*)w.leaf_boxes;
+    float4* table = (float4*)w.box_table;
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(grid_for(n)), dim3(BLOCK), 0, s, sorted, moving, n, shutter_t0, shutter_t1, leaf);
     RTL_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_fit, dim3(grid_for(n)), dim3(BLOCK), 0, s, sorted, moving, n, shutter_t0, shutter_t1, nodes, w.parent_inner,
-                       w.parent_leaf, w.arrived);
+    hipLaunchKernelGGL(k_block_boxes, dim3(grid_for(nb)), dim3(BLOCK), 0, s, leaf, n, nb, table);
+    RTL_TRY(hipGetLastError());
+    for (uint32_t k = 1; k < levels; k++) {
+        hipLaunchKernelGGL(k_table_level, dim3(grid_for(nb)), dim3(BLOCK), 0, s, table, nb, k);
+        RTL_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_hierarchy, dim3(grid_for(n - 1)), dim3(BLOCK), 0, s, keys, n, prim_base, node_base, nodes, w.parent_inner,
+                       w.parent_leaf, leaf, table, nb);
     RTL_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_depth, dim3(grid_for(n)), dim3(BLOCK), 0, s, n, w.parent_inner, w.parent_leaf, w.scalars + 12);
     RTL_TRY(hipGetLastError());
