@@ -193,7 +193,18 @@ def bounce_bytes_per_ray(info, primary_frac, alive_frac, nodes_per_ray, prims_pe
             56.0 * alive_frac + 16.0 * (1.0 - alive_frac))
 
 
-def measured_traffic(workload, kernel):
+def profiled_size_matches(doc, width, spp):
+    """A committed profile summary speaks for a run only if it was taken at the same --width / --spp overrides (0 = the
+    workload's own size): per-launch figures do not carry over to launches of another size."""
+    import re
+    cmd = doc.get("command", "")
+    def opt(name):
+        m = re.search(rf"--{name}[ =](\d+)", cmd)
+        return int(m.group(1)) if m else 0
+    return opt("width") == (width or 0) and opt("spp") == (spp or 0)
+
+
+def measured_traffic(workload, kernel, width=0, spp=0):
     """(HBM bytes, file, launches) of a kernel over the profiled run, from the newest committed PMC summary of this workload
     (profiles/*_<workload>_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc
     passes of this script, the read side doubled as gfx950 needs).  None when no summary matches."""
@@ -203,7 +214,7 @@ def measured_traffic(workload, kernel):
             doc = json.loads(f.read_text())
         except (OSError, ValueError):
             continue
-        if doc.get("kernel", "").startswith(kernel) and doc.get("bytes_per_step"):
+        if doc.get("kernel", "").startswith(kernel) and doc.get("bytes_per_step") and profiled_size_matches(doc, width, spp):
             launches = max(doc.get("dispatches_fetch_pass", 0), 1)
             best = (doc["read_bytes"] + doc["write_bytes"], f.name, launches)
     return best
@@ -252,22 +263,22 @@ def cpu_baseline(frames_cfg, width, aspect, seconds_target=20.0):
                       f"oracle BVHNode path (oracle/rt_oracle.cpp), {sec_total:.1f} s"}
 
 
-def pmc_profile(workload, kernel):
+def pmc_profile(workload, kernel, width=0, spp=0):
     """VALU counters of the dominant kernel from the newest committed PMC summary of this workload
     (profiles/*_<workload>_<kernel>_pmc.json: valu_busy = share of SIMD cycles that issue a VALU instruction,
     lane_use = active lanes per VALU instruction / 64).  None when no summary matches."""
     best = None
-    for f in sorted((ROOT / "profiles").glob(f"*_{workload}_{kernel}_pmc.json")):
+    for f in sorted((ROOT / "profiles").glob(f"*_{workload}*_{kernel}_pmc.json")):
         try:
             doc = json.loads(f.read_text())
         except (OSError, ValueError):
             continue
-        if "valu_busy" in doc and "lane_use" in doc:
+        if "valu_busy" in doc and "lane_use" in doc and profiled_size_matches(doc, width, spp):
             best = {"valu_busy": doc["valu_busy"], "lane_use": doc["lane_use"], "source": f.name}
     return best
 
 
-def kernel_rooflines(frames, stats, steps, workload, use_committed):
+def kernel_rooflines(frames, stats, steps, workload, use_committed, width=0, spp=0):
     """Per-kernel HBM roofline figures of a set of timed steps.  stats: one list of per-frame rt_render stats per
     step.  Every kernel is charged the bytes it has to move itself (never another formulation's); a scene that
     fits one XCD's L2 is charged once per XCD and launch, a larger one per node fetch and primitive test, and where
@@ -308,7 +319,7 @@ def kernel_rooflines(frames, stats, steps, workload, use_committed):
              ("k_bounce", sums["bounce_ms"], bo_bytes, launches["bounce_kernel_launches"]), ("k_paths", sums["paths_ms"], pa_bytes, launches["paths_launches"])]
 
     def one(name, ms, nbytes, nl):
-        t = measured_traffic(workload, name) if use_committed else None
+        t = measured_traffic(workload, name, width, spp) if use_committed else None
         traffic = round(t[0] * 1.0 / max(t[2], 1), 1) if t else None  # per launch of the profiled run
         per_launch = nbytes / max(nl, 1)
         source = "algorithmic"
@@ -324,7 +335,7 @@ def kernel_rooflines(frames, stats, steps, workload, use_committed):
         d = {"kernel": name, "achieved": round(ach, 2), "frac": round(ach / PEAK_HBM_GBPS, 5), "launches": int(nl),
              "avg_launch_ms": round(ms / max(nl, 1), 5), "algorithmic_bytes_per_launch": round(per_launch, 1), "bytes_source": source,
              "traffic": traffic, "traffic_source": t[1] if t else None}
-        pmc = pmc_profile(workload, name) if use_committed else None
+        pmc = pmc_profile(workload, name, width, spp) if use_committed else None
         if pmc:
             d["valu"] = pmc
         return d
@@ -500,7 +511,7 @@ def main():
         # dominant kernel and its roofline, from HIP events recorded around every launch of the timed steps
         roof = None
         if not args.no_profile:
-            roof = kernel_rooflines(frames, stats, args.steps, args.workload, use_committed=not (args.spp or args.width))
+            roof = kernel_rooflines(frames, stats, args.steps, args.workload, use_committed=True, width=args.width, spp=args.spp)
             if at_once:
                 # the frames share the GPU, so a kernel's HIP-event time includes the time it waited for the others'
                 # waves: the per-kernel figures of such a run are upper bounds of the time, lower bounds of the rate
