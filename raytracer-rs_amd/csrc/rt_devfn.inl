@@ -168,9 +168,6 @@ DEV f3 rand_in_unit_sphere(Rng& r) {  // vec3_helpers.rs:25-31
     for (;;) {
         float x = r.range_pm1(), y = r.range_pm1(), z = r.range_pm1();
         f3 p{x, y, z};
-#ifdef EXP_ONE_TRY
-        return p;
-#endif
         if (!(dot3(p, p) >= 1.0f)) return p;
     }
 }
@@ -437,11 +434,7 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     double len = (double)(G.has_xform ? len3(wd) : __builtin_sqrtf(a));  // (without a transform a is |wd|^2 already)
     double inside = (double)(r2 - r1) / len;
     double xi = medium_xi(k0, k1, bounce, G.order);
-#ifdef EXP_F32_LOG
-    double hit_distance = G.neg_inv_density * (double)__logf((float)xi);
-#else
     double hit_distance = G.neg_inv_density * log(xi);
-#endif
     if (hit_distance > inside) return;
     best.t = r1 + (float)(hit_distance / len);
     best.prim = HIT_MEDIUM_BIT | g;
@@ -729,9 +722,6 @@ template <bool COUNT>
 DEV void apply_media(const Scene& S, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce, Hit& best,
                      TraceCount* cnt) {
     for (uint32_t m = 0; m < S.n_media; m++) {
-#ifdef EXP_NO_MEDIA
-        continue;
-#endif
         test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
         if (COUNT) cnt->prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);  // two boundary queries
     }
@@ -969,9 +959,6 @@ DEV f3 tex_value(const Scene& S, const LdsTables& L, uint32_t ti, float u, float
     if (kind == TK_NOISE) {  // texture.rs:78-82
         const uint32_t table = __float_as_uint(T1.w);
         float turb;
-#ifdef EXP_NO_NOISE
-        return {0.5f, 0.5f, 0.5f};
-#endif
         if (L.has_perlin0 && table == 0u)
             turb = perlin_turb(*L.perlin0, p, 7);
         else
