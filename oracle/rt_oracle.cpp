@@ -1179,6 +1179,22 @@ void build_nested_instances(orc_scene& S, Stream& axis_rng) {
     S.world.add_shape(mk<TransformedObject>(turned, m4_translation(v3(265, 0, 295))));
     cornell_camera(S);
 }
+// Not a reference preset: media whose boundary is more than one object (ConstantMedium<T: Hittable>,
+// src/shapes.rs:624-646).  Mirrors medium_cluster() of the host library.
+void build_medium_cluster(orc_scene& S) {
+    cornell_walls(S.world, v3(7, 7, 7), 113.0f, 127.0f, 443.0f, 432.0f);
+    Scene balls;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++)
+                balls.add_shape(mk<Sphere>(v3(218.0f + 60.0f * (float)i, 150.0f + 60.0f * (float)j, 218.0f + 60.0f * (float)k), 45.0f,
+                                           mk<DielectricMat>(1.5f)));
+    // (a Scene as the boundary: with a BVHNode the answer would depend on which boxes of its random tree lie behind the
+    // ray origin, src/aabb.rs:21-33)
+    S.world.add_shape(mk<ConstantMedium>(mk<Scene>(balls), 0.02f, v3(0.9f, 0.9f, 0.9f)));
+    S.world.add_shape(mk<ConstantMedium>(mk<Box2>(v3(40, 0, 60), v3(160, 120, 180), mk<DielectricMat>(1.5f)), 0.03f, v3(0.1f, 0.1f, 0.4f)));
+    cornell_camera(S);
+}
 void build_final_scene(orc_scene& S, Stream& rng, Stream& axis_rng, const uint8_t* img, int iw, int ih) {  // src/main.rs:240-305
     Scene& s = S.world;
     Scene boxes;
@@ -1329,6 +1345,8 @@ orc_scene* orc_scene_create(const char* name, uint32_t seed, const uint8_t* img,
         build_cornell_smoke(*S);
     else if (n == "nested_instances")
         build_nested_instances(*S, axis);
+    else if (n == "medium_cluster")
+        build_medium_cluster(*S);
     else if (n == "final_scene")
         build_final_scene(*S, rng, axis, img, iw, ih);
     else if (n == "synth_spheres")

@@ -770,14 +770,22 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
                 ghi[k] = std::max(ghi[k], it.hi[k]);
             }
         const bool medium = G.kind == RT_GROUP_MEDIUM;
-        if (medium && mem.size() > rtd::MAX_LEAF_PRIMS)
-            return fail(c, RT_ERR_UNSUPPORTED, "medium boundary with more than 16 primitives");
+        // (a boundary is tested primitive by primitive, twice per ray: the limit keeps a mistake from hanging the device)
+        if (medium && mem.size() > 65536) return fail(c, RT_ERR_UNSUPPORTED, "medium boundary with more than 65536 primitives");
         if (medium && media_groups.size() >= 64) return fail(c, RT_ERR_UNSUPPORTED, "more than 64 media");
         const bool single = medium || (mem_tests <= 8 && items.size() == mem.size());
         std::vector<uint32_t> order;
         const uint32_t base = (uint32_t)prims.size();
-        rtb::Result r = rtb::build(items, leaf_max, single, base, nodes, order);
-        for (uint32_t oi : order) prims.push_back(make_prim(c, mem[oi], moving));
+        rtb::Result r;
+        if (medium) {  // the boundary's primitives in id order (Scene::intersect order), no tree
+            for (const PrimSrc& ps : mem) prims.push_back(make_prim(c, ps, moving));
+            r.root_ref = rtd::make_prim_ref(base, (uint32_t)std::min<size_t>(mem.size(), rtd::MAX_LEAF_PRIMS));
+            r.depth = 0;
+            D.depth = (uint32_t)mem.size();
+        } else {
+            r = rtb::build(items, leaf_max, single, base, nodes, order);
+            for (uint32_t oi : order) prims.push_back(make_prim(c, mem[oi], moving));
+        }
         D.root_ref = r.root_ref;
         if (!mem.empty() && mem.size() <= 64) D.flat_range = base | ((uint32_t)(mem.size() - 1) << 26);
         memcpy(D.blo, glo, sizeof(glo));

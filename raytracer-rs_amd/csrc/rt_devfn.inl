@@ -301,9 +301,11 @@ DEV void test_prim(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time,
     best.key = id;
 }
 
-// Scene::intersect over a short primitive list (scene.rs:27-41); only t is needed by the medium.
-DEV bool list_closest(const Scene& S, uint32_t ref, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out) {
-    uint32_t first = ref & 0x03FFFFFFu, cnt = ((ref >> 26) & 15u) + 1u;
+// Primitives of a medium's boundary: they sit in one run from (root_ref & 0x03FFFFFF) on; a medium is never nested,
+// so its Group::depth holds their number.
+DEV uint32_t medium_boundary_count(const Group& G) { return G.depth; }
+// Scene::intersect over a primitive list (scene.rs:27-41), however long; only t is needed by the medium.
+DEV bool list_closest(const Scene& S, uint32_t first, uint32_t cnt, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out) {
     float closest = tmax;
     bool any = false;
     for (uint32_t i = 0; i < cnt; i++) {
@@ -407,7 +409,7 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     }
     float a = dot3(d, d);
     float r1, r2;
-    const uint32_t first = G.root_ref & 0x03FFFFFFu, cnt = ((G.root_ref >> 26) & 15u) + 1u;
+    const uint32_t first = G.root_ref & 0x03FFFFFFu, cnt = medium_boundary_count(G);
     // The first boundary query runs over the whole line (shapes.rs:655); a line that misses the widened box
     // of the boundary misses every primitive of it, so the exact tests are skipped for it.  (A single primitive
     // rejects a line that misses it as early as the box would.)
@@ -424,8 +426,9 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     } else if (cnt <= 8u) {
         if (!boundary_pair(S, first, cnt, o, d, a, time, r1, r2)) return;
     } else {
-        if (!list_closest(S, G.root_ref, o, d, a, time, -INF_F, INF_F, r1)) return;
-        if (!list_closest(S, G.root_ref, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
+        // any longer list (ConstantMedium<T> takes any Hittable, shapes.rs:624-646): both queries test every primitive
+        if (!list_closest(S, first, cnt, o, d, a, time, -INF_F, INF_F, r1)) return;
+        if (!list_closest(S, first, cnt, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
     }
     if (r1 < tmin) r1 = tmin;
     if (r2 > best.t) r2 = best.t;
@@ -723,7 +726,7 @@ DEV void apply_media(const Scene& S, f3 wo, f3 wd, float time, float tmin, uint3
                      TraceCount* cnt) {
     for (uint32_t m = 0; m < S.n_media; m++) {
         test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
-        if (COUNT) cnt->prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);  // two boundary queries
+        if (COUNT) cnt->prims += 2u * medium_boundary_count(S.groups[S.media[m]]);  // two boundary queries
     }
 }
 // Closest surface hit of one ray in a flat scene (Scene::flat): the world primitives, then each instance's

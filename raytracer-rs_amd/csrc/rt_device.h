@@ -70,7 +70,7 @@ struct alignas(16) Group {
     float m[12];     // object -> world, rows
     float minv[12];  // world -> object
     double neg_inv_density;
-    uint32_t root_ref;  // instance: BLAS root; medium: REF_PRIMS list of the boundary (media are not BVH leaves)
+    uint32_t root_ref;  // instance: BLAS root; medium: first boundary primitive in bits 25..0 (media are not BVH leaves; count in depth)
     uint32_t mat;
     uint32_t kind;      // 1 instance, 2 medium
     uint32_t has_xform;
@@ -80,7 +80,7 @@ struct alignas(16) Group {
     // An instance may sit inside another instance (TransformedObject<T> takes any Hittable, shapes.rs:26-41): parent
     // is the enclosing instance group or -1, depth the number of instances around this one (at most MAX_NESTING - 1).
     int32_t parent;
-    uint32_t depth;
+    uint32_t depth;  // (a medium: the number of primitives of its boundary)
 };
 constexpr uint32_t MAX_NESTING = 4u;
 constexpr uint32_t FLAT_NONE = 0xFFFFFFFFu;

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
     w.cur = REF_EMPTY;
     uint32_t media_prims = 0;
     if (COUNT && GROUPS)
-        for (uint32_t m = 0; m < S.n_media; m++) media_prims += 2u * (((S.groups[S.media[m]].root_ref >> 26) & 15u) + 1u);
+        for (uint32_t m = 0; m < S.n_media; m++) media_prims += 2u * medium_boundary_count(S.groups[S.media[m]]);
     uint32_t rounds = 0, busy_lanes = 0;  // instrumented build: loop rounds of this wave and the lanes that held a ray in them
     for (;;) {
         const unsigned long long idle = __ballot(!have);

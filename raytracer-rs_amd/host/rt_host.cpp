@@ -160,6 +160,27 @@ Scene nested_instances() {
     return s;
 }
 
+// Not a reference preset either: media whose boundary is more than one object, which ConstantMedium<T: Hittable>
+// (shapes.rs:624-646) allows -- a Scene of 27 overlapping spheres, and an untransformed box -- in the Cornell shell.
+// (A Scene, not a BVHNode: the reference's box test rejects boxes behind the ray origin whatever interval it is asked
+// about, aabb.rs:21-33, so which objects a BVH boundary offers to the medium's first query over the whole line depends
+// on its randomly built tree.  The device evaluates either as the list of objects, Scene::intersect, scene.rs:27-41.)
+Scene medium_cluster() {
+    Scene s = Scene::new_();
+    cornell_shell(s, Vec3A(7.0f, 7.0f, 7.0f), Vec2(113.0f, 127.0f), Vec2(443.0f, 432.0f));
+    Scene balls = Scene::new_();
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++)
+                balls.add_shape(Sphere::new_(Vec3A(218.0f + 60.0f * (float)i, 150.0f + 60.0f * (float)j, 218.0f + 60.0f * (float)k), 45.0f,
+                                             DielectricMat::new_(1.5f)));
+    s.add_shape(ConstantMedium<Scene>::from_color(balls, 0.02f, Vec3A(0.9f, 0.9f, 0.9f)));
+    s.add_shape(ConstantMedium<Box2>::from_color(Box2::full_box(Vec3A(40.0f, 0.0f, 60.0f), Vec3A(160.0f, 120.0f, 180.0f),
+                                                                std::make_shared<DielectricMat>(DielectricMat::new_(1.5f))),
+                                                 0.03f, Vec3A(0.1f, 0.1f, 0.4f)));
+    return s;
+}
+
 Scene final_scene() {  // main.rs:240-305
     Scene s = Scene::new_();
     Scene boxes = Scene::new_();
@@ -274,8 +295,9 @@ void* rth_scene_build(const char* name, uint32_t seed, const char* earthmap_path
             p.origin = Vec3A(26.0f, 3.0f, 6.0f);
             p.target = Vec3A(0.0f, 2.0f, 0.0f);
             p.background = Vec3A::ZERO();
-        } else if (n == "cornell_box" || n == "cornell_smoke" || n == "nested_instances") {
-            b->world = n == "cornell_box" ? cornell_box() : (n == "cornell_smoke" ? cornell_smoke() : nested_instances());
+        } else if (n == "cornell_box" || n == "cornell_smoke" || n == "nested_instances" || n == "medium_cluster") {
+            b->world = n == "cornell_box" ? cornell_box()
+                                          : (n == "cornell_smoke" ? cornell_smoke() : (n == "nested_instances" ? nested_instances() : medium_cluster()));
             p.origin = Vec3A(278.0f, 278.0f, -800.0f);
             p.target = Vec3A(278.0f, 278.0f, 0.0f);
             p.fov_deg = 40.0f;

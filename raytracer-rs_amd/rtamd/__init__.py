@@ -20,7 +20,7 @@ LIB_DIR = Path(__import__("os").environ.get("RTAMD_LIB_DIR", PKG_DIR / "lib"))
 EARTHMAP = REPO_ROOT / "tests" / "golden" / "earthmap.ppm"
 
 SCENES = ("random_world", "two_spheres", "two_perlin_spheres", "earth", "simple_light", "cornell_box",
-          "cornell_smoke", "final_scene", "nested_instances", "synth_spheres")
+          "cornell_smoke", "final_scene", "nested_instances", "medium_cluster", "synth_spheres")
 
 RT_OK = 0
 STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPPORTED", -4: "RT_ERR_NOT_COMMITTED",

@@ -242,13 +242,21 @@ def test_error_paths(gpu_ctx):
     ctx.set_scene(spheres=moving, materials=mats, textures=texs, shutter=(0.0, 2.0))
     ctx.render(8, 8, late, 1)
     ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0]), materials=mats, textures=texs)
-    # a medium boundary of more than 16 primitives (ConstantMedium<T> takes any T, shapes.rs:624-646; the device
-    # evaluates the boundary as one primitive list): refused at commit with the limit in the message
+    # a medium boundary of any number of primitives is taken (ConstantMedium<T> takes any T, shapes.rs:624-646; the
+    # device evaluates the boundary as one primitive list) up to a limit that is there to catch mistakes
+    mats2 = mats + [rtamd.rt_material(kind=4, tex=0)]
     many = dict(c0r=[[float(i), 0, 0, 0.4] for i in range(17)], mat=[0] * 17, id=list(range(17)), group=[1] * 17)
-    fog = rtamd.rt_group(kind=2, has_xform=0, neg_inv_density=-1.0, mat=0)
+    fog = rtamd.rt_group(kind=2, has_xform=0, neg_inv_density=-1e-3, mat=1)
+    ctx.set_scene(spheres=many, groups=[fog], materials=mats2, textures=texs)
+    r = ctx.intersect(one_ray((16, 0, -5), (0, 0, 1)))  # through the last of the 17 spheres, extremely dense: scatters at its surface
+    assert r["prim"][0] == -2 and r["t"][0] == pytest.approx(4.6, abs=0.02)
+    r = ctx.intersect(one_ray((16.9, 0, -5), (0, 0, 1)))  # past all of them
+    assert r["prim"][0] == -1
+    n_big = 65537
+    huge = dict(c0r=np.tile(np.array([[0, 0, 0, 0.4]], np.float32), (n_big, 1)), mat=[0] * n_big, id=list(range(n_big)), group=[1] * n_big)
     with pytest.raises(rtamd.RtError) as e:
-        ctx.set_scene(spheres=many, groups=[fog], materials=mats, textures=texs)
-    assert e.value.code == -3 and "16" in str(e.value)
+        ctx.set_scene(spheres=huge, groups=[fog], materials=mats2, textures=texs)
+    assert e.value.code == -3 and "65536" in str(e.value)
     with pytest.raises(rtamd.RtError):
         ctx.intersect(one_ray((0, 0, 0), (0, 0, 1)))  # the failed commit left no scene behind
     # groups inside groups (rt_group.parent): instances up to four deep; anything else is refused by name
@@ -305,7 +313,8 @@ def test_golden_images(gpu_ctx, name):
 # ---- image parity with the oracle at equal spp -------------------------------------------------------
 @pytest.mark.parametrize("name,aspect", [("random_world", 16 / 9), ("two_spheres", 16 / 9), ("two_perlin_spheres", 16 / 9),
                                          ("earth", 16 / 9), ("simple_light", 16 / 9), ("cornell_box", 1.0),
-                                         ("cornell_smoke", 1.0), ("final_scene", 1.0), ("nested_instances", 1.0)])
+                                         ("cornell_smoke", 1.0), ("final_scene", 1.0), ("nested_instances", 1.0),
+                                         ("medium_cluster", 1.0)])
 def test_image_matches_oracle_at_equal_spp(gpu_ctx, name, aspect):
     w, spp = 160, 8
     h = rtamd.image_height(w, aspect)
@@ -400,7 +409,7 @@ def test_rank_split_sample_split_and_batch_size_change_no_bit(gpu_ctx):
 
 
 @pytest.mark.parametrize("name", ["random_world", "cornell_smoke", "final_scene", "two_perlin_spheres", "earth", "cornell_box",
-                                  "nested_instances"])
+                                  "nested_instances", "medium_cluster"])
 def test_fused_and_split_pipelines_give_the_same_bits(name):
     w, h, spp = 150, 100, 5
     ctx = rtamd.Context(0)
