@@ -112,7 +112,8 @@ typedef struct rt_group {
     /* 0: the group stands in the world.  Otherwise 1 + index of the instance group it stands inside
      * (TransformedObject<T> takes any Hittable, shapes.rs:26-41: a transformed object inside a transformed object).
      * The enclosing group comes earlier in the array and is an instance; at most 4 instances are stacked.  A
-     * primitive's `group` names the innermost instance around it.  Media cannot be nested (RT_ERR_UNSUPPORTED). */
+     * primitive's `group` names the innermost instance around it.  A medium may stand inside instances (it is then
+     * handed their ray); nothing may stand inside a medium beyond the one transform of its boundary (RT_ERR_UNSUPPORTED). */
     uint32_t parent;
 } rt_group;
 

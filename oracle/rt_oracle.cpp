@@ -531,6 +531,9 @@ struct Hittable;
 struct Ids {
     int prim = 0, inst = 0, medium = 0;
     std::vector<const Hittable*> media;  // every ConstantMedium, in creation order
+    // for each of them the TransformedObjects it stands inside, outermost first (empty for a medium in the world)
+    std::vector<std::vector<const Hittable*>> media_inside;
+    std::vector<const Hittable*> inside_now;  // (while the ids are handed out)
 };
 struct Hittable {
     virtual ~Hittable() {}
@@ -768,10 +771,11 @@ struct TransformedObject : Hittable {  // src/shapes.rs:26-97
         aabb.min = vmin(p0, vmin(p1, vmin(p2, vmin(p3, vmin(p4, vmin(p5, vmin(p6, p7)))))));
         aabb.max = vmax(p0, vmax(p1, vmax(p2, vmax(p3, vmax(p4, vmax(p5, vmax(p6, p7)))))));
     }
-    bool intersect(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
-        Ray local{m4_point(inv_transform, ray.origin), m4_vector(inv_transform, ray.direction), ray.time};
-        HitRecord rec;
-        if (!object->intersect(local, t_min, t_max, rec)) return false;
+    Ray to_local(const Ray& ray) const {
+        return Ray{m4_point(inv_transform, ray.origin), m4_vector(inv_transform, ray.direction), ray.time};
+    }
+    // src/shapes.rs:74-88: the object's record taken out into the space of `ray`
+    void to_outside(const Ray& ray, const HitRecord& rec, HitRecord& out) const {
         V3 normal = normalize(m4_vector(transform, rec.normal));
         V3 point = m4_point(transform, rec.point);
         out = rec;
@@ -779,6 +783,12 @@ struct TransformedObject : Hittable {  // src/shapes.rs:26-97
         out.normal = normal;
         out.inst_id = id;
         out.set_face_normal(ray, normal);
+    }
+    bool intersect(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+        Ray local = to_local(ray);
+        HitRecord rec;
+        if (!object->intersect(local, t_min, t_max, rec)) return false;
+        to_outside(ray, rec, out);
         return true;
     }
     bool bounding_box(float, float, AABB& out) const override {
@@ -787,7 +797,9 @@ struct TransformedObject : Hittable {  // src/shapes.rs:26-97
     }
     void assign_ids(Ids& ids) override {
         id = ids.inst++;
+        ids.inside_now.push_back(this);
         object->assign_ids(ids);
+        ids.inside_now.pop_back();
     }
 };
 
@@ -829,7 +841,12 @@ struct ConstantMedium : Hittable {  // src/shapes.rs:624-705
     void assign_ids(Ids& ids) override {
         id = ids.medium++;
         ids.media.push_back(this);
+        ids.media_inside.push_back(ids.inside_now);
+        // (the boundary's own objects are not "inside" anything as far as the media are concerned)
+        std::vector<const Hittable*> keep;
+        keep.swap(ids.inside_now);
         boundary->assign_ids(ids);
+        keep.swap(ids.inside_now);
     }
 };
 
@@ -973,17 +990,29 @@ inline Ray camera_sample_ray(const Camera& cam, int w, int h, int i, int j, Stre
 }
 
 // world.intersect with media evaluated last (see the file header)
+// A medium inside TransformedObjects, asked through them as the nested intersect calls of src/shapes.rs:64-92 would:
+// each level takes the ray into its object's space and the record back out.
+bool medium_through(const std::vector<const Hittable*>& inside, size_t level, const Hittable* m, const Ray& ray, float t_min, float t_max,
+                    HitRecord& out) {
+    if (level == inside.size()) return m->intersect(ray, t_min, t_max, out);
+    const TransformedObject* T = static_cast<const TransformedObject*>(inside[level]);
+    HitRecord rec;
+    if (!medium_through(inside, level + 1, m, T->to_local(ray), t_min, t_max, rec)) return false;
+    T->to_outside(ray, rec, out);
+    return true;
+}
 struct World {
     const Hittable* surfaces;                 // the Scene or its BVHNode
-    const std::vector<const Hittable*>* media;  // top-level ConstantMedium objects, creation order
+    const std::vector<const Hittable*>* media;  // every ConstantMedium, creation order
+    const std::vector<std::vector<const Hittable*>>* media_inside;
     bool intersect(const Ray& ray, float t_min, float t_max, HitRecord& out) const {
         g_media_deferred = true;
         bool any = surfaces->intersect(ray, t_min, t_max, out);
         g_media_deferred = false;
         float closest = any ? out.t : t_max;
-        for (const Hittable* m : *media) {
+        for (size_t k = 0; k < media->size(); k++) {
             HitRecord rec;
-            if (m->intersect(ray, t_min, closest, rec)) {  // scene.rs:33-37: taken unchecked
+            if (medium_through((*media_inside)[k], 0, (*media)[k], ray, t_min, closest, rec)) {  // scene.rs:33-37: taken unchecked
                 closest = rec.t;
                 out = rec;
                 any = true;
@@ -1175,6 +1204,12 @@ void build_nested_instances(orc_scene& S, Stream& axis_rng) {
         inner.add_shape(mk<TransformedObject>(ball, m4_translation(v3(120, 60, 100))));
     }
     inner.add_shape(mk<Box2>(v3(0, 0, 0), v3(165, 100, 165), mk<LambertianMat>(white)));
+    inner.add_shape(mk<ConstantMedium>(mk<Sphere>(v3(100, 170, 60), 45.0f, mk<DielectricMat>(1.5f)), 0.05f, v3(0.2f, 0.4f, 0.9f)));
+    {
+        HPtr fog = mk<ConstantMedium>(mk<Box2>(v3(0, 0, 0), v3(120, 90, 120), mk<DielectricMat>(1.5f)), 0.02f, v3(0.9f, 0.9f, 0.9f));
+        M4 place = m4_mul(m4_translation(v3(30, 330, 200)), m4_rotation_y(degree_to_rad(25.0f)));
+        S.world.add_shape(mk<TransformedObject>(fog, place));
+    }
     HPtr turned = mk<TransformedObject>(BVHNode::from_scene(inner, 0.0f, 1.0f, axis_rng), m4_rotation_y(degree_to_rad(15.0f)));
     S.world.add_shape(mk<TransformedObject>(turned, m4_translation(v3(265, 0, 295))));
     cornell_camera(S);
@@ -1277,7 +1312,7 @@ Camera scene_camera(const orc_scene& S, float aspect) {  // src/main.rs:454-456
                         0.0f, 1.0f);
 }
 World world_of(const orc_scene& S, int mode) {
-    return World{mode == 1 ? static_cast<const Hittable*>(S.bvh.get()) : static_cast<const Hittable*>(&S.world), &S.ids.media};
+    return World{mode == 1 ? static_cast<const Hittable*>(S.bvh.get()) : static_cast<const Hittable*>(&S.world), &S.ids.media, &S.ids.media_inside};
 }
 Ray ray_from7(const float* r) { return Ray{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, r[6]}; }
 void rec_to_out(bool hit, const HitRecord& rec, float out[11]) {

@@ -663,8 +663,8 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     }
     for (const rt_group& g : c->groups)
         if (g.kind == RT_GROUP_MEDIUM && g.mat >= nm) return fail(c, RT_ERR_INVALID, "medium: material out of range");
-    // Instances inside instances (rt_group::parent): the enclosing group comes first in the array, is an instance
-    // itself, and at most MAX_NESTING instances are stacked.  Media stay at the top level.
+    // Groups inside instances (rt_group::parent): the enclosing group comes first in the array and is an instance; at
+    // most MAX_NESTING instances are stacked.  A medium may stand inside instances; nothing stands inside a medium.
     std::vector<uint32_t> nest_depth(ng, 0);
     std::vector<std::vector<uint32_t>> children(ng);
     bool nested = false;
@@ -673,12 +673,13 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         if (G.parent == 0) continue;
         if (G.parent > g) return fail(c, RT_ERR_INVALID, "group: parent must be a group earlier in the array");
         const rt_group& P = c->groups[G.parent - 1];
-        if (G.kind == RT_GROUP_MEDIUM) return fail(c, RT_ERR_UNSUPPORTED, "a medium nested inside another group is not supported");
-        if (P.kind != RT_GROUP_INSTANCE) return fail(c, RT_ERR_UNSUPPORTED, "an instance nested inside a medium boundary is not supported");
+        if (P.kind != RT_GROUP_INSTANCE)
+            return fail(c, RT_ERR_UNSUPPORTED, "a group nested inside a medium (its boundary or the medium itself) is not supported");
         nest_depth[g] = nest_depth[G.parent - 1] + 1;
+        nested = true;
+        if (G.kind == RT_GROUP_MEDIUM) continue;  // a medium inside instances: handed their ray, evaluated after the surfaces like any medium
         if (nest_depth[g] >= rtd::MAX_NESTING) return fail(c, RT_ERR_UNSUPPORTED, "instances nested more than 4 deep");
         children[G.parent - 1].push_back(g);
-        nested = true;
     }
 
     // bucket primitives by group, in id order inside a group (Scene::intersect order for medium boundaries)

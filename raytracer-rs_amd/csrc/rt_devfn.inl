@@ -399,9 +399,13 @@ DEV f3 fast_rcp3(f3 d);
 // ConstantMedium::intersect (shapes.rs:648-701).  wo/wd: the world ray.  A medium that reports a hit
 // replaces the closest hit so far unchecked, as Scene::intersect does (scene.rs:33-37): its final_t may
 // lie beyond best.t because shapes.rs:676-683 divides by the ray length twice.
+// NESTED: media may stand inside instances (the scene's kernels are compiled for that); such a medium is handed the ray
+// of the instance around it, as the nested intersect calls of shapes.rs:64-92 would.
+template <bool NESTED>
 DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1,
                      uint32_t bounce, Hit& best) {
     const Group& G = S.groups[g];
+    if (NESTED && G.parent >= 0) instance_ray(S, G.parent, wo, wd);  // (the same in every lane)
     f3 o = wo, d = wd;
     if (G.has_xform) {  // TransformedObject as the boundary (shapes.rs:66-70); t is shared between spaces
         o = xf_point(G.minv, wo);
@@ -434,7 +438,7 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     if (r2 > best.t) r2 = best.t;
     if (r1 >= r2) return;
     if (r1 < 0.0f) r1 = 0.0f;
-    double len = (double)(G.has_xform ? len3(wd) : __builtin_sqrtf(a));  // (without a transform a is |wd|^2 already)
+    double len = (double)(G.has_xform ? len3(wd) : __builtin_sqrtf(a));  // (without a boundary transform a is |wd|^2 already)
     double inside = (double)(r2 - r1) / len;
     double xi = medium_xi(k0, k1, bounce, G.order);
     double hit_distance = G.neg_inv_density * log(xi);
@@ -721,11 +725,11 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
 }
 // ConstantMedium objects come after all surfaces, in creation order (the order of a Scene whose media were
 // added last), and override the closest surface hit unchecked (scene.rs:33-37).
-template <bool COUNT>
+template <bool COUNT, bool NESTED>
 DEV void apply_media(const Scene& S, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce, Hit& best,
                      TraceCount* cnt) {
     for (uint32_t m = 0; m < S.n_media; m++) {
-        test_medium(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
+        test_medium<NESTED>(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
         if (COUNT) cnt->prims += 2u * medium_boundary_count(S.groups[S.media[m]]);  // two boundary queries
     }
 }
@@ -768,7 +772,7 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
                    uint32_t bounce, Hit& best, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
     if (FLAT) {
         trace_flat<GROUPS != 0, COUNT>(S, wo, wd, time, tmin, tmax, best, cnt);
-        if (GROUPS) apply_media<COUNT>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
+        if (GROUPS) apply_media<COUNT, GROUPS == 2>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
         return;
     }
     Walk w;
@@ -778,7 +782,7 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
         walk_leaf<STRIDE, GROUPS, COUNT>(S, w, wo, wd, time, tmin, stk, overflow_flag, cnt);
     }
     best = w.best;
-    if (GROUPS) apply_media<COUNT>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
+    if (GROUPS) apply_media<COUNT, GROUPS == 2>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
 }
 
 // ---- hit record (hit_record.rs, shapes.rs) --------------------------------------
@@ -788,27 +792,48 @@ struct Record {
     bool front;
     uint32_t mat;
 };
+// shapes.rs:74-88 at every instance from grp outwards, innermost first: normal through M (not its inverse transpose),
+// point through M, then face-set again against the ray that instance was handed (wo, wd: the world ray).
+template <bool NESTED>
+DEV void record_to_world(const Scene& S, int grp, f3 wo, f3 wd, f3& point, f3& normal, bool& front) {
+    for (int a = grp; a >= 0; a = NESTED ? S.groups[a].parent : -1) {
+        const Group& G = S.groups[a];
+        if (!G.has_xform) continue;
+        f3 nw = normalize3(xf_vector(G.m, normal));
+        point = xf_point(G.m, point);
+        f3 lo = wo, ld = wd;
+        if (NESTED && G.parent >= 0) instance_ray(S, G.parent, lo, ld);
+        front = dot3(ld, nw) < 0.0f;
+        normal = front ? nw : -nw;
+    }
+}
 DEV void sphere_uv(f3 p, float& u, float& v) {  // shapes.rs:19-24
     float theta = acosf(-p.y);
     float phi = atan2f(-p.z, p.x) + PI_F;
     u = phi / (2.0f * PI_F);
     v = theta / PI_F;
 }
-template <bool WANT_UV>
+// NESTED: the scene has groups inside instances (Scene::nested); kernels are compiled for either case, so that the
+// common one does not carry the loops over the levels.
+template <bool WANT_UV, bool NESTED>
 DEV void make_record(const Scene& S, const LdsTables& L, f3 wo, f3 wd, float time, const Hit& h, Record& rec) {
     if (h.prim & HIT_MEDIUM_BIT) {  // shapes.rs:690-697
         const Group& G = S.groups[h.prim & 0x3FFFFFFFu];
-        rec.point = wo + (h.t * wd);
+        f3 bo = wo, bd = wd;  // the ray the medium was handed
+        const bool inside = NESTED && G.parent >= 0;
+        if (inside) instance_ray(S, G.parent, bo, bd);
+        rec.point = bo + (h.t * bd);
         rec.normal = {1.0f, 0.0f, 0.0f};
         rec.front = true;
         rec.u = 0.0f;
         rec.v = 0.0f;
         rec.mat = G.mat;
+        if (inside) record_to_world<NESTED>(S, G.parent, wo, wd, rec.point, rec.normal, rec.front);
         return;
     }
     f3 o = wo, d = wd;
     if (h.grp >= 0) {
-        if (S.nested) {
+        if (NESTED) {
             instance_ray(S, h.grp, o, d);
         } else if (S.groups[h.grp].has_xform) {
             o = xf_point(S.groups[h.grp].minv, wo);
@@ -847,18 +872,7 @@ DEV void make_record(const Scene& S, const LdsTables& L, f3 wo, f3 wd, float tim
     }
     bool front = dot3(d, outward) < 0.0f;  // hit_record.rs:32-42
     f3 normal = front ? outward : -outward;
-    // shapes.rs:74-88 at every instance around the primitive, innermost first: normal through M (not its inverse
-    // transpose), then face-set again against the ray that instance was handed
-    for (int a = h.grp; a >= 0; a = S.nested ? S.groups[a].parent : -1) {
-        const Group& G = S.groups[a];
-        if (!G.has_xform) continue;
-        f3 nw = normalize3(xf_vector(G.m, normal));
-        point = xf_point(G.m, point);
-        f3 lo = wo, ld = wd;
-        if (S.nested && G.parent >= 0) instance_ray(S, G.parent, lo, ld);
-        front = dot3(ld, nw) < 0.0f;
-        normal = front ? nw : -nw;
-    }
+    record_to_world<NESTED>(S, h.grp, wo, wd, point, normal, front);
     rec.point = point;
     rec.normal = normal;
     rec.front = front;

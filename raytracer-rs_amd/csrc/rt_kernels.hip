@@ -114,6 +114,7 @@ DEV void end_path(const rtk::RenderConst& rc, float4* __restrict__ radiance, uin
     if (rc.radiance_cleared && L.x == 0.0f && L.y == 0.0f && L.z == 0.0f) return;
     radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
 }
+template <bool NESTED>
 DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderConst& rc, PathRegs& p, const Hit& h, uint32_t bounce,
                     float4* __restrict__ radiance) {
     if (h.prim == HIT_NONE) {  // main.rs:60-62
@@ -133,9 +134,9 @@ DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderCons
     const Material M = load_material(S, tabs, mi);
     Record rec;
     if (material_needs_uv(M))
-        make_record<true>(S, tabs, p.o, p.d, p.time, h, rec);
+        make_record<true, NESTED>(S, tabs, p.o, p.d, p.time, h, rec);
     else
-        make_record<false>(S, tabs, p.o, p.d, p.time, h, rec);
+        make_record<false, NESTED>(S, tabs, p.o, p.d, p.time, h, rec);
     Rng rng{p.k0, p.k1, bounce << 24};
     f3 att{1.0f, 1.0f, 1.0f}, dir{0.0f, 0.0f, 0.0f};
     const f3 color = material_color(S, tabs, M, rec);
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
                 cyc[1] += t1 - t0;
                 t0 = t1;
             }
-            alive = shade_path(S, L, rc, p, h, bounce, radiance);
+            alive = shade_path<GROUPS == 2>(S, L, rc, p, h, bounce, radiance);
             if (COUNT) {
                 asm volatile("" ::"v"(p.o.x), "v"(p.d.x), "v"(p.T.x));
                 t1 = __builtin_amdgcn_s_memtime();
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
     }
 }
 
+template <bool NESTED>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
                                                        const float4* __restrict__ hits, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ radiance) {
@@ -465,8 +467,8 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             h.prim = __float_as_uint(hv.y);
             h.grp = __float_as_int(hv.z);
             h.key = __float_as_uint(hv.w);
-            if (S.n_media) apply_media<false>(S, p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h, nullptr);
-            alive = shade_path(S, L, rc, p, h, bounce, radiance);
+            if (S.n_media) apply_media<false, NESTED>(S, p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h, nullptr);
+            alive = shade_path<NESTED>(S, L, rc, p, h, bounce, radiance);
         }
         compact_store(clds, parity, alive, p, out, out_count, shard_base);
     }
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
             Hit h;
             trace_ray<rtk::BLOCK, GROUPS, FLAT, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, b, h, stk, overflow_flag, nullptr);
             rays++;
-            if (!shade_path(S, L, rc, p, h, b, radiance)) break;
+            if (!shade_path<GROUPS == 2>(S, L, rc, p, h, b, radiance)) break;
         }
     }
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
                 Hit h;
                 trace_ray<rtk::BLOCK, GROUPS, FLAT, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk, overflow_flag, nullptr);
                 rays++;
-                if (shade_path(S, L, rc, p, h, bounce, radiance))
+                if (shade_path<GROUPS == 2>(S, L, rc, p, h, bounce, radiance))
                     bounce++;
                 else
                     have = false;
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
         rec.normal = {0, 0, 0};
         rec.u = rec.v = 0.0f;
         rec.front = false;
-        if (hit) make_record<true>(S, no_tables, wo, wd, time, h, rec);
+        if (hit) make_record<true, GROUPS == 2>(S, no_tables, wo, wd, time, h, rec);
         if (prim) {
             int32_t id = -1;
             if (hit) {
@@ -667,6 +669,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_intersect_batch(Scene S, unsigne
         }
         if (inst) {  // the instance the record came out of last: the outermost one around the primitive (shapes.rs:74-88)
             int g = hit ? h.grp : -1;
+            if (hit && (h.prim & HIT_MEDIUM_BIT)) g = S.groups[h.prim & 0x3FFFFFFFu].parent;  // a medium inside instances
             while (g >= 0 && S.groups[g].parent >= 0) g = S.groups[g].parent;
             inst[i] = g >= 0 ? (int32_t)S.groups[g].order : -1;
         }
@@ -831,8 +834,12 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
 hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc, PathState in, PathState out,
                         const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance) {
     const size_t smem = table_bytes(scene);
-    hipLaunchKernelGGL(k_shade, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade, oversubscription(), smem)), dim3(BLOCK), smem, s,
-                       scene, rc, in, out, hits, q, bounce, radiance);
+    if (scene.nested)
+        hipLaunchKernelGGL(k_shade<true>, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<true>, oversubscription(), smem)), dim3(BLOCK), smem, s,
+                           scene, rc, in, out, hits, q, bounce, radiance);
+    else
+        hipLaunchKernelGGL(k_shade<false>, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<false>, oversubscription(), smem)), dim3(BLOCK), smem, s,
+                           scene, rc, in, out, hits, q, bounce, radiance);
     return hipGetLastError();
 }
 

@@ -134,8 +134,8 @@ Scene cornell_smoke() {  // main.rs:207-238
 
 // Not a reference preset: the Cornell shell around transformed objects INSIDE transformed objects, which the
 // reference's types allow (TransformedObject<T: Hittable>, shapes.rs:26-41) and none of its scenes uses.  One block is
-// a translation around a rotation around a box; the other stacks four transforms (translate, rotate, a BVH of three
-// objects, two of them transformed again, one of those twice).
+// a translation around a rotation around a box; the other stacks four transforms (translate, rotate, a BVH of five
+// objects, two of them transformed again, one of those twice, one a medium); a third is a medium inside a transform.
 Scene nested_instances() {
     Scene s = Scene::new_();
     cornell_shell(s, Vec3A(15.0f, 15.0f, 15.0f), Vec2(213.0f, 227.0f), Vec2(343.0f, 332.0f));
@@ -155,6 +155,14 @@ Scene nested_instances() {
     inner.add_shape(TransformedObject<Sphere>::new_(Sphere::new_(Vec3A(0.0f, 0.0f, 0.0f), 30.0f, DielectricMat::new_(1.5f)),
                                                     Mat4::from_translation(Vec3(120.0f, 60.0f, 100.0f))));
     inner.add_shape(Box2::new_(165.0f, 100.0f, 165.0f, LambertianMat::from_color(white)));
+    // a medium two transforms deep (it is handed the ray of the inner one), and below one alone inside a transform
+    inner.add_shape(ConstantMedium<Sphere>::from_color(Sphere::new_(Vec3A(100.0f, 170.0f, 60.0f), 45.0f, DielectricMat::new_(1.5f)), 0.05f,
+                                                       Vec3A(0.2f, 0.4f, 0.9f)));
+    {
+        auto fog = ConstantMedium<Box2>::from_color(Box2::new_(120.0f, 90.0f, 120.0f, DielectricMat::new_(1.5f)), 0.02f, Vec3A(0.9f, 0.9f, 0.9f));
+        Mat4 place = Mat4::from_translation(Vec3(30.0f, 330.0f, 200.0f)) * Mat4::from_rotation_y(degree_to_rad(25.0f));
+        s.add_shape(TransformedObject<ConstantMedium<Box2>>::new_(fog, place));
+    }
     auto turned = TransformedObject<BVHNode>::new_(BVHNode::from_scene(inner, 0.0f, 1.0f), Mat4::from_rotation_y(degree_to_rad(15.0f)));
     s.add_shape(TransformedObject<TransformedObject<BVHNode>>::new_(turned, Mat4::from_translation(Vec3(265.0f, 0.0f, 295.0f))));
     return s;

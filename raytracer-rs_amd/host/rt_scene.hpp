@@ -605,9 +605,13 @@ struct ConstantMedium : Hittable {
         return ConstantMedium(std::move(boundary), -1.0 / (double)density, std::make_shared<IsotropicMat>(IsotropicMat::from_color(color)));
     }
     void flatten(FlatScene& fs, uint32_t group) const override {
-        if (group != 0) throw std::runtime_error("ConstantMedium nested inside another group is not supported on the device");
+        // inside TransformedObjects: the medium names the innermost one as its parent; inside another medium: not on the device
+        for (uint32_t a = group; a != 0; a = fs.groups[a - 1].parent)
+            if (fs.groups[a - 1].kind != RT_GROUP_INSTANCE)
+                throw std::runtime_error("ConstantMedium nested inside a ConstantMedium boundary is not supported on the device");
         rt_group g{};
         g.kind = RT_GROUP_MEDIUM;
+        g.parent = group;
         g.neg_inv_density = negative_density;
         g.mat = material->flatten(fs);
         const Hittable* inner = &boundary;

@@ -1,6 +1,7 @@
 // Host-logic check (no GPU) of what the C++ mirror of the reference's scene API accepts: the reference lets
 // TransformedObject<T> and ConstantMedium<T> wrap any Hittable (shapes.rs:26-41, 624-646); the device takes up to four
-// transforms stacked inside each other, and media at the top level whose boundary carries at most one transform.
+// transforms stacked inside each other, and media in the world or inside such transforms whose boundary carries at most
+// one transform of its own.
 // Anything else must be refused with a message that says so -- never flattened into something else.
 #include <cstdio>
 #include <cstring>
@@ -62,9 +63,19 @@ int main() {
         }
         ok &= refuses("five stacked transforms", [&](FlatScene& f5) { T5::new_(t4, turn).flatten(f5, 0); }, "more than 4 deep");
     }
-    ok &= refuses("medium inside transform", [&](FlatScene& fs) {
+    {  // medium inside transform: an (empty) instance group and a medium that names it as its parent
+        FlatScene fs;
         auto fog = ConstantMedium<Sphere>::from_color(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), 0.1f, Vec3A(1, 1, 1));
         TransformedObject<ConstantMedium<Sphere>>::new_(fog, shift).flatten(fs, 0);
+        if (fs.groups.size() != 2 || fs.groups[0].kind != RT_GROUP_INSTANCE || fs.groups[1].kind != RT_GROUP_MEDIUM || fs.groups[1].parent != 1 ||
+            fs.sph_group.size() != 1 || fs.sph_group[0] != 2) {
+            std::printf("FAIL medium inside transform\n");
+            ok = false;
+        }
+    }
+    ok &= refuses("medium inside a medium's boundary", [&](FlatScene& fs) {
+        auto fog = ConstantMedium<Sphere>::from_color(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), 0.1f, Vec3A(1, 1, 1));
+        ConstantMedium<ConstantMedium<Sphere>>::from_color(fog, 0.1f, Vec3A(1, 1, 1)).flatten(fs, 0);
     }, "nested");
     ok &= refuses("transform inside the transform a medium wraps", [&](FlatScene& fs) {
         auto inner = TransformedObject<Sphere>::new_(Sphere::new_(Vec3A(0, 0, 0), 1.0f, DielectricMat::new_(1.5f)), turn);

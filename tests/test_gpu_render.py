@@ -163,6 +163,18 @@ def test_kat_instance_inside_instance(gpu_ctx):
         imgs.append(img)
     gpu_ctx.set_pipeline(-1)
     assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2]) and imgs[0].min() < 8.0 * 0.9
+    # a medium inside the outer instance (TransformedObject<ConstantMedium<Sphere>>): boundary sphere of radius 2 at the
+    # origin of the instance's space, i.e. at (10, 0, 0); extremely dense, so it scatters where the ray enters
+    mats.append(rtamd.rt_material(kind=4, tex=0))
+    fog = rtamd.rt_group(kind=2, has_xform=0, neg_inv_density=-1e-3, mat=1, parent=1)
+    gpu_ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 2]], mat=[0], id=[0], group=[2]), groups=[outer, fog], materials=mats, textures=texs)
+    r = gpu_ctx.intersect(one_ray((10, 0, -5), (0, 0, 1)))
+    assert r["prim"][0] == -2 and r["inst"][0] == 0 and r["t"][0] == pytest.approx(3.0, abs=0.02)
+    # the medium's own record says normal (1, 0, 0), front face; the instance around it face-sets it again against the
+    # ray (shapes.rs:86): dot((0,0,1), (1,0,0)) = 0 is not < 0, so the normal is flipped and the face is "back"
+    assert r["point"][0] == pytest.approx([10.0, 0.0, -2.0], abs=0.02) and r["normal"][0].tolist() == [-1.0, 0.0, 0.0] and r["front"][0] == 0
+    r = gpu_ctx.intersect(one_ray((0, 0, -5), (0, 0, 1)))  # where the sphere would be without the instance's shift
+    assert r["prim"][0] == -1
 
 
 def test_empty_medium_group_is_never_hit(gpu_ctx):
@@ -265,8 +277,9 @@ def test_error_paths(gpu_ctx):
     with pytest.raises(rtamd.RtError) as e:
         ctx.set_scene(spheres=one, groups=[inst(2), inst()], materials=mats, textures=texs)  # parent after child
     assert e.value.code == -1 and "parent" in str(e.value)
-    with pytest.raises(rtamd.RtError) as e:
-        ctx.set_scene(spheres=one, groups=[inst(), rtamd.rt_group(kind=2, neg_inv_density=-1.0, mat=0, parent=1)], materials=mats, textures=texs)
+    with pytest.raises(rtamd.RtError) as e:  # a medium inside a medium
+        fogs = [rtamd.rt_group(kind=2, neg_inv_density=-1.0, mat=0), rtamd.rt_group(kind=2, neg_inv_density=-1.0, mat=0, parent=1)]
+        ctx.set_scene(spheres=dict(c0r=[[0, 0, 0, 1]], mat=[0], id=[0], group=[2]), groups=fogs, materials=mats, textures=texs)
     assert e.value.code == -3 and "medium" in str(e.value)
     with pytest.raises(rtamd.RtError) as e:
         ctx.set_scene(spheres=one, groups=[rtamd.rt_group(kind=2, neg_inv_density=-1.0, mat=0), inst(1)], materials=mats, textures=texs)
