@@ -301,9 +301,12 @@ DEV void test_prim(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float time,
     best.key = id;
 }
 
-// Primitives of a medium's boundary: they sit in one run from (root_ref & 0x03FFFFFF) on; a medium is never nested,
-// so its Group::depth holds their number.
-DEV uint32_t medium_boundary_count(const Group& G) { return G.depth; }
+// Primitives of a medium's boundary: they sit in one run from (root_ref & 0x03FFFFFF) on; nothing stands inside a
+// medium, so its Group::depth is free to hold their number.
+DEV uint32_t medium_boundary_count(const Group& G) {
+    const uint32_t short_count = ((G.root_ref >> 26) & 15u) + 1u;  // up to 15 primitives: in the reference itself; 16 stands for "16 or more"
+    return short_count < 16u ? short_count : G.depth;
+}
 // Scene::intersect over a primitive list (scene.rs:27-41), however long; only t is needed by the medium.
 DEV bool list_closest(const Scene& S, uint32_t first, uint32_t cnt, f3 o, f3 d, float a, float time, float tmin, float tmax, float& t_out) {
     float closest = tmax;
@@ -413,7 +416,9 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
     }
     float a = dot3(d, d);
     float r1, r2;
-    const uint32_t first = G.root_ref & 0x03FFFFFFu, cnt = medium_boundary_count(G);
+    // (cnt: 16 stands for "16 or more"; the exact number is only looked up where the long list is walked -- with the
+    // count an unknown from memory the short, common forms below compile to slower code)
+    const uint32_t first = G.root_ref & 0x03FFFFFFu, cnt = ((G.root_ref >> 26) & 15u) + 1u;
     // The first boundary query runs over the whole line (shapes.rs:655); a line that misses the widened box
     // of the boundary misses every primitive of it, so the exact tests are skipped for it.  (A single primitive
     // rejects a line that misses it as early as the box would.)
@@ -431,8 +436,9 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
         if (!boundary_pair(S, first, cnt, o, d, a, time, r1, r2)) return;
     } else {
         // any longer list (ConstantMedium<T> takes any Hittable, shapes.rs:624-646): both queries test every primitive
-        if (!list_closest(S, first, cnt, o, d, a, time, -INF_F, INF_F, r1)) return;
-        if (!list_closest(S, first, cnt, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
+        const uint32_t n = medium_boundary_count(G);
+        if (!list_closest(S, first, n, o, d, a, time, -INF_F, INF_F, r1)) return;
+        if (!list_closest(S, first, n, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
     }
     if (r1 < tmin) r1 = tmin;
     if (r2 > best.t) r2 = best.t;
@@ -832,12 +838,18 @@ DEV void make_record(const Scene& S, const LdsTables& L, f3 wo, f3 wd, float tim
         return;
     }
     f3 o = wo, d = wd;
+    const Group* G = nullptr;  // (scenes without nesting) the one instance around the primitive, if it has a transform
     if (h.grp >= 0) {
         if (NESTED) {
             instance_ray(S, h.grp, o, d);
-        } else if (S.groups[h.grp].has_xform) {
-            o = xf_point(S.groups[h.grp].minv, wo);
-            d = xf_vector(S.groups[h.grp].minv, wd);
+        } else {
+            G = S.groups + h.grp;
+            if (G->has_xform) {
+                o = xf_point(G->minv, wo);
+                d = xf_vector(G->minv, wd);
+            } else {
+                G = nullptr;
+            }
         }
     }
     float4 A, B;
@@ -872,7 +884,14 @@ DEV void make_record(const Scene& S, const LdsTables& L, f3 wo, f3 wd, float tim
     }
     bool front = dot3(d, outward) < 0.0f;  // hit_record.rs:32-42
     f3 normal = front ? outward : -outward;
-    record_to_world<NESTED>(S, h.grp, wo, wd, point, normal, front);
+    if (NESTED) {
+        record_to_world<NESTED>(S, h.grp, wo, wd, point, normal, front);
+    } else if (G) {  // shapes.rs:74-88: normal through M (not its inverse transpose), then face-set again
+        f3 nw = normalize3(xf_vector(G->m, normal));
+        point = xf_point(G->m, point);
+        front = dot3(wd, nw) < 0.0f;
+        normal = front ? nw : -nw;
+    }
     rec.point = point;
     rec.normal = normal;
     rec.front = front;
