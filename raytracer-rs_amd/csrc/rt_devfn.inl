@@ -633,9 +633,11 @@ DEV void inner_step_wide(const Scene& S, Walk& w, float tmin, const Stack& stk, 
         }
     }
 }
-template <int STRIDE, bool COUNT>
+// WIDTH: 2 / 4 = the kernel is compiled for the binary / the four-child walk only (the persistent trace kernel: the
+// binary walk alone needs 64 instead of 72 registers, one more resident wave per SIMD); 0 = whichever the scene holds.
+template <int STRIDE, bool COUNT, int WIDTH = 0>
 DEV void inner_step(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt) {
-    if (S.wide) {  // (the same in every lane)
+    if (WIDTH == 4 || (WIDTH == 0 && S.wide)) {  // (the same in every lane)
         inner_step_wide<STRIDE, COUNT>(S, w, tmin, stk, overflow_flag, cnt);
         return;
     }
@@ -670,9 +672,9 @@ DEV void inner_step(const Scene& S, Walk& w, float tmin, const Stack& stk, uint3
     }
 }
 // Walks inner nodes only (at most max_steps of them), until cur is a leaf, an instance, a sentinel or empty.
-template <int STRIDE, bool COUNT>
+template <int STRIDE, bool COUNT, int WIDTH = 0>
 DEV void walk_inner(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
-    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) inner_step<STRIDE, COUNT>(S, w, tmin, stk, overflow_flag, cnt);
+    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) inner_step<STRIDE, COUNT, WIDTH>(S, w, tmin, stk, overflow_flag, cnt);
 }
 // One non-inner step: tests a leaf's primitives, enters an instance or leaves it, then takes the next entry
 // from the stack.  No-op when cur is an inner node or empty.

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 7
 #endif
-template <int GROUPS, bool COUNT, bool FLAT>
+// WIDTH: children per inner node the walk is compiled for (2 or 4; a launch picks the one the scene holds)
+template <int GROUPS, bool COUNT, bool FLAT, int WIDTH>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES))) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
                                                        uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS, uint32_t lds_entries,
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
             if (have) busy_lanes++;
         }
         if (have) {
-            walk_inner<rtk::BLOCK, COUNT>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
+            walk_inner<rtk::BLOCK, COUNT, WIDTH>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
             // (without instances the walk never leaves world space: its own copy of the ray is the world ray, and keeping
             // a second one would cost the kernel a resident wave per SIMD)
             if (GROUPS) {
@@ -810,9 +811,14 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
     // from.  When few rays are queued, launch fewer blocks rather than shorter runs: at least min_run rays per wave.
     static const int min_run = env_factor("RTAMD_TRACE_MIN_RUN", 16) * 8;  // in units of 8 rays (env_factor caps at 64)
     blocks_per_shard = std::max(1u, (blocks_per_shard * BLOCK + (BLOCK / 64) * min_run - 1) / ((BLOCK / 64) * min_run));
-#define RT_CALL(G, C, F)                                                                                                         \
+#define RT_CALL(G, C, F)                                       \
+    do {                                                       \
+        if (scene.wide) RT_TRACE(G, C, F, 4);                  \
+        else RT_TRACE(G, C, F, 2);                             \
+    } while (0)
+#define RT_TRACE(G, C, F, W)                                                                                                     \
     do {                                                                                                                         \
-        const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C, F>, trace_oversubscription(), smem);         \
+        const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C, F, W>, trace_oversubscription(), smem);      \
         const size_t need = (size_t)deep * grid * BLOCK * sizeof(uint32_t);                                                      \
         if (need > spill.bytes) {                                                                                                \
             if (spill.p) (void)hipFree(spill.p);                                                                                 \
@@ -822,12 +828,13 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
             if (e != hipSuccess) return e;                                                                                       \
             spill.bytes = need;                                                                                                  \
         }                                                                                                                        \
-        hipLaunchKernelGGL((k_trace<G, C, F>), dim3(grid), block, smem, s, scene, in, q, bounce, hits, stats, overflow_flag,     \
+        hipLaunchKernelGGL((k_trace<G, C, F, W>), dim3(grid), block, smem, s, scene, in, q, bounce, hits, stats, overflow_flag,  \
                            (uint32_t)env_factor("RTAMD_REFILL", 24), env_factor("RTAMD_INNER_STEPS", 4), lds_entries,            \
                            (uint32_t*)spill.p);                                                                                  \
     } while (0)
     RT_DISPATCH_TRACE_CFG(cfg, scene.flat != 0u, RT_CALL);
 #undef RT_CALL
+#undef RT_TRACE
     return hipGetLastError();
 }
 
