@@ -495,6 +495,9 @@ template <int STRIDE>
 DEV uint32_t stack_get(const Stack& st, int sp) {
     const uint32_t at = (uint32_t)sp < st.lds_cap ? (uint32_t)sp : 0u;
     uint32_t v = st.lds[at * STRIDE];
+    // (the value is pinned here: otherwise the compiler sinks this read into the branch below and merges the two into
+    // one flat load of a selected address after all)
+    asm volatile("" : "+v"(v));
     if ((uint32_t)sp >= st.lds_cap) v = st.spill[(size_t)((uint32_t)sp - st.lds_cap) * st.spill_stride];
     return v;
 }
