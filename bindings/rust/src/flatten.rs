@@ -186,12 +186,13 @@ pub fn check(ctx: *mut rt_ctx, rc: i32) -> Result<(), String> {
 // group's members; a TransformedObject boundary hands its matrices to the group (shapes.rs:226-235 wraps
 // Transformed(Box2)); the boundary's own material is never used (shapes.rs:690-697)
 //     fn flatten(&self, fs: &mut FlatScene, group: u32) {
-//         assert_eq!(group, 0, "ConstantMedium nested inside another group is not supported on the device");
+//         // group != 0: the medium stands inside TransformedObjects and names the innermost one as its parent (the
+//         // library refuses a medium inside another medium's boundary with RT_ERR_UNSUPPORTED at rt_scene_commit)
 //         let mat = fs.material(&self.material);                      // the Isotropic phase function
 //         match self.boundary.as_transformed() {
-//             Some((m, minv, inner)) => { let g = fs.add_group(RT_GROUP_MEDIUM, Some((m, minv)), self.negative_density, mat, 0);
+//             Some((m, minv, inner)) => { let g = fs.add_group(RT_GROUP_MEDIUM, Some((m, minv)), self.negative_density, mat, group);
 //                                         inner.flatten(fs, g); }
-//             None => { let g = fs.add_group(RT_GROUP_MEDIUM, None, self.negative_density, mat, 0);
+//             None => { let g = fs.add_group(RT_GROUP_MEDIUM, None, self.negative_density, mat, group);
 //                       self.boundary.flatten(fs, g); }
 //         }
 //     }

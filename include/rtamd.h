@@ -67,7 +67,8 @@ int rt_ctx_set_tail_paths(rt_ctx* ctx, uint64_t tail_paths);
  *           "later shape wins" rule of scene.rs:32-38);
  *   group : 0 = top level world, g > 0 = member of groups[g-1].
  * A group is what TransformedObject<T> (shapes.rs:26-97) or ConstantMedium<T>
- * (shapes.rs:624-705) wraps. */
+ * (shapes.rs:624-705) wraps.  Groups may stand inside instance groups (rt_group.parent): transformed objects
+ * inside transformed objects, up to four deep, and media inside them. */
 typedef enum rt_material_kind {
     RT_MAT_LAMBERTIAN = 0,    /* materials.rs:45-61  : tex */
     RT_MAT_METAL = 1,         /* materials.rs:84-95  : albedo, fuzz (caller clamps to <=1 as MetalMat::new does) */
