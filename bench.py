@@ -65,8 +65,12 @@ def log(*a):
 class Frame:
     """One scene of the workload on this rank: context, camera, accumulation buffer, gather plan."""
 
-    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=32, gather_on_cpu=False, own_stream=False,
+    def __init__(self, name, width, aspect, spp, rank, world, device, n_synth, tile=None, gather_on_cpu=False, own_stream=False,
                  exchange="torch"):
+        # 16x16 tiles split a frame evenly over up to four ranks (and are the fastest pixel order on one); eight ranks
+        # want 8x8 tiles (final_scene 800x800, slowest of eight ranks: 57.4 ms with 16, 54.6 ms with 8, per 1024 spp)
+        if tile is None:
+            tile = 16 if world <= 4 else 8
         self.name, self.w, self.spp = name, width, spp
         self.h = rtamd.image_height(width, aspect)
         self.rank, self.world = rank, world
@@ -523,7 +527,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "frames": list(frames_cfg), "width": width, "height": frames[0].h,
-                       "spp": spp, "max_depth": MAX_DEPTH, "tile_split": f"32x32 tiles round-robin over {world} rank(s)",
+                       "spp": spp, "max_depth": MAX_DEPTH, "tile_split": f"{frames[0].tile}x{frames[0].tile} tiles round-robin over {world} rank(s)",
                        "frames_at_once": bool(at_once), "exchange": frames[0].exchange_kind, "bvh_width": [f.info.get("bvh_width", 2) for f in frames],
                        "rays_per_step": rays / args.steps, "paths_per_step": paths / args.steps,
                        "sec_per_frame": round(elapsed / args.steps / len(frames), 5)},

@@ -21,7 +21,7 @@ pub fn render(world: &Scene, camera: &Camera, background: Vec3A, image_width: u3
 
     let cam = camera.to_ffi();
     let params = rt_render_params { width: image_width, height: image_height, sample0: 0, sample1: samples_per_pixel,
-                                    max_depth: max_depth as u32, background: background.into(), seed: 1, tile_size: 32,
+                                    max_depth: max_depth as u32, background: background.into(), seed: 1, tile_size: 16,
                                     rank: 0, nranks: 1, reserved: 0 };
     let n = (image_width * image_height) as usize;
     let mut sum = vec![0f32; 3 * n];

@@ -1235,7 +1235,7 @@ int rt_intersect_batch_noalloc(rt_ctx* c, uint64_t n, const float* ox, const flo
 int rt_owned_pixels(uint32_t width, uint32_t height, uint32_t tile_size, uint32_t rank, uint32_t nranks, uint32_t* out,
                     uint64_t cap, uint64_t* n_out) {
     if (!n_out || !width || !height) return RT_ERR_INVALID;
-    if (!tile_size) tile_size = 32;
+    if (!tile_size) tile_size = RT_DEFAULT_TILE;
     if (!nranks) nranks = 1;
     if (rank >= nranks) return RT_ERR_INVALID;
     const uint32_t tx = (width + tile_size - 1) / tile_size, ty = (height + tile_size - 1) / tile_size;
@@ -1344,7 +1344,7 @@ int rt_pack_owned(rt_ctx* c, uint32_t width, uint32_t height, uint32_t tile_size
     if (!is_device_ptr(accum_rgb) || !is_device_ptr(packed)) return fail(c, RT_ERR_INVALID, "rt_pack_owned: device pointers expected");
     HIP_TRY(c, hipSetDevice(c->device));
     rtk::TileDeal d;
-    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : 32, nranks, d))) return rc;
+    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : RT_DEFAULT_TILE, nranks, d))) return rc;
     HIP_TRY(c, rtk::launch_pack_owned(c->stream, d, rank, accum_rgb, packed));
     return RT_OK;
 }
@@ -1357,7 +1357,7 @@ int rt_scatter_gathered(rt_ctx* c, uint32_t width, uint32_t height, uint32_t til
     if (!is_device_ptr(gathered) || !is_device_ptr(frame_rgb)) return fail(c, RT_ERR_INVALID, "rt_scatter_gathered: device pointers expected");
     HIP_TRY(c, hipSetDevice(c->device));
     rtk::TileDeal d;
-    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : 32, nranks, d))) return rc;
+    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : RT_DEFAULT_TILE, nranks, d))) return rc;
     HIP_TRY(c, rtk::launch_scatter_gathered(c->stream, d, gathered, c->deal_block_pixels, frame_rgb));
     return RT_OK;
 }
@@ -1438,7 +1438,7 @@ int rt_gather_frame(rt_ctx* c, uint32_t width, uint32_t height, uint32_t tile_si
         d_out = (float*)c->d_xout.p;
     }
     rtk::TileDeal d;
-    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : 32, nranks, d))) return rc;
+    if ((rc = prepare_deal(c, width, height, tile_size ? tile_size : RT_DEFAULT_TILE, nranks, d))) return rc;
     const uint64_t block = c->deal_block_pixels;  // every rank's share, padded to the largest
     if ((rc = ensure(c, c->d_gathered, (size_t)nranks * block * 3 * sizeof(float)))) return rc;
     float* gathered = (float*)c->d_gathered.p;
@@ -1483,7 +1483,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     // and still hit in a flat scene.  gen_range(time_start..time_end) draws from [time_start, time_end).
     if (c->has_moving && !(cam->time_start >= std::min(c->shutter_t0, c->shutter_t1) && cam->time_end <= std::max(c->shutter_t0, c->shutter_t1)))
         return fail(c, RT_ERR_INVALID, "rt_render: camera time range lies outside the shutter interval of rt_scene_commit (the scene has moving spheres)");
-    const uint32_t ts = p->tile_size ? p->tile_size : 32, nranks = p->nranks ? p->nranks : 1;
+    const uint32_t ts = p->tile_size ? p->tile_size : RT_DEFAULT_TILE, nranks = p->nranks ? p->nranks : 1;
     if (p->rank >= nranks) return fail(c, RT_ERR_INVALID, "rt_render: rank >= nranks");
     HIP_TRY(c, hipSetDevice(c->device));
     auto wall0 = std::chrono::steady_clock::now();

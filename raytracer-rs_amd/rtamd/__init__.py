@@ -19,6 +19,7 @@ REPO_ROOT = PKG_DIR.parent
 LIB_DIR = Path(__import__("os").environ.get("RTAMD_LIB_DIR", PKG_DIR / "lib"))
 EARTHMAP = REPO_ROOT / "tests" / "golden" / "earthmap.ppm"
 
+DEFAULT_TILE = 16  # RT_DEFAULT_TILE of include/rtamd.h: side of the tiles a frame is dealt to the ranks in
 SCENES = ("random_world", "two_spheres", "two_perlin_spheres", "earth", "simple_light", "cornell_box",
           "cornell_smoke", "final_scene", "nested_instances", "medium_cluster", "synth_spheres")
 
@@ -246,7 +247,7 @@ def camera_new(origin, target, up, vfov_rad, aspect, aperture, focus, t0, t1):
     return cam
 
 
-def owned_pixels(width, height, tile_size=32, rank=0, nranks=1):
+def owned_pixels(width, height, tile_size=DEFAULT_TILE, rank=0, nranks=1):
     n = C.c_uint64(0)
     core().rt_owned_pixels(width, height, tile_size, rank, nranks, None, 0, C.byref(n))
     out = np.empty(n.value, dtype=np.uint32)
@@ -254,7 +255,7 @@ def owned_pixels(width, height, tile_size=32, rank=0, nranks=1):
     return out
 
 
-def frame_block_pixels(width, height, tile_size=32, nranks=1):
+def frame_block_pixels(width, height, tile_size=DEFAULT_TILE, nranks=1):
     """Pixels of the largest share of any rank: the size of one rank's block in the frame exchange."""
     n = C.c_uint64(0)
     rc = core().rt_frame_block_pixels(width, height, tile_size, nranks, C.byref(n))
@@ -531,7 +532,7 @@ class Context:
         return out
 
     def render(self, width, height, cam, spp, depth=50, seed=1, background=None, sample0=0, accum=None,
-               tile_size=32, rank=0, nranks=1):
+               tile_size=DEFAULT_TILE, rank=0, nranks=1):
         """Adds samples [sample0, sample0+spp) into accum ((h,w,3) f32; numpy or torch CUDA) and returns
         (accum, stats dict)."""
         if accum is None:
@@ -558,7 +559,7 @@ class Context:
     def comm_destroy(self):
         self._check(self.L.rt_comm_destroy(self.h))
 
-    def gather_frame(self, accum, tile_size=32, out=None):
+    def gather_frame(self, accum, tile_size=DEFAULT_TILE, out=None):
         """One collective per frame: (h, w, 3) with this rank's tiles filled in -> the complete frame on every rank."""
         _check_array(accum, "accum", "float32", (None, None, 3), self.device)
         h, w = int(accum.shape[0]), int(accum.shape[1])

@@ -13,7 +13,7 @@ from . import owned_pixels
 
 
 class TileGather:
-    def __init__(self, width, height, rank, world, device, tile=32, owned_fn=owned_pixels):
+    def __init__(self, width, height, rank, world, device, tile=16, owned_fn=owned_pixels):
         self.w, self.h, self.rank, self.world = width, height, rank, world
         owned = [owned_fn(width, height, tile, r, world) for r in range(world)]
         total = sum(len(o) for o in owned)
