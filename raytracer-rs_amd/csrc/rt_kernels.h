@@ -45,7 +45,12 @@ struct RenderConst {
 struct Batch {
     const uint32_t* pixel_list;  // owned pixels of this chunk, row << 16 | column
     uint32_t npix, sample0, n_samples;
-    double inv_npix;             // 1.0 / npix
+    // Slot layout of a batch.  A run of 64 slots (the camera rays of one wave) holds 64 >> q_log2 neighbouring pixels
+    // of the list times 1 << q_log2 consecutive samples: slot = (s / q) * q * npix + (p / w) * 64 + (s % q) * w + p % w
+    // with q = 1 << q_log2, w = 64 / q.  q_log2 = 0: plainly slot = s * npix + p.  (q > 1 needs npix % w == 0 and
+    // n_samples % q == 0.)
+    double inv_qnpix;            // 1.0 / (q * npix)
+    uint32_t q_log2;
 };
 
 struct TraceCfg {

@@ -44,14 +44,20 @@ struct PathRegs {
 DEV void camera_path(const rtk::RenderConst& rc, const rtk::Batch& b, uint32_t slot, PathRegs& p) {
     // slot / npix through the f64 reciprocal: the product is within 2^-20 of the quotient, so the truncation is
     // off by at most one, which the remainder test repairs (an integer divide costs ~30 instructions)
-    uint32_t sl = (uint32_t)((double)slot * b.inv_npix);
-    uint32_t pl = slot - sl * b.npix;
+    const uint32_t qn = b.npix << b.q_log2;
+    uint32_t sl = (uint32_t)((double)slot * b.inv_qnpix);
+    uint32_t pl = slot - sl * qn;
     if ((int32_t)pl < 0) {
         sl--;
-        pl += b.npix;
-    } else if (pl >= b.npix) {
+        pl += qn;
+    } else if (pl >= qn) {
         sl++;
-        pl -= b.npix;
+        pl -= qn;
+    }
+    if (b.q_log2) {  // (the same in every lane) see rtk::Batch: 64 slots = a few pixels x a few samples
+        const uint32_t lane = pl & 63u, w_log2 = 6u - b.q_log2;
+        sl = (sl << b.q_log2) + (lane >> w_log2);
+        pl = ((pl >> 6) << w_log2) + (lane & ((1u << w_log2) - 1u));
     }
     const uint32_t sample = b.sample0 + sl;
     const uint32_t packed = b.pixel_list[pl];  // row << 16 | column
@@ -566,8 +572,11 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_accumulate(const float4* __restr
         const uint32_t pixel = (packed >> 16) * width + (packed & 0xFFFFu);
         float* a = accum_rgb + 3ull * pixel;
         float r = a[0], g = a[1], b = a[2];
+        const uint32_t w_log2 = 6u - batch.q_log2, q_mask = (1u << batch.q_log2) - 1u;
+        const unsigned long long at_pixel = (unsigned long long)(pl >> w_log2) * 64u + (pl & ((1u << w_log2) - 1u));
         for (uint32_t s = 0; s < batch.n_samples; s++) {
-            float4 L = radiance[(unsigned long long)s * batch.npix + pl];
+            float4 L = radiance[(unsigned long long)(s >> batch.q_log2) * ((unsigned long long)batch.npix << batch.q_log2) + at_pixel +
+                                ((s & q_mask) << w_log2)];
             r = r + L.x;
             g = g + L.y;
             b = b + L.z;
