@@ -27,4 +27,8 @@ for arg in sys.argv[1:]:
     dt, st = best
     print(f"{tag:14s} {name:18s} {spp:4d} spp {dt*1e3:8.2f} ms {st['rays']/dt/1e6:8.1f} Mrays/s | trace {st['trace_ms']:7.2f} shade {st['shade_ms']:7.2f} "
           f"bounce {st['bounce_ms']:7.2f} tail {st['tail_ms']:5.2f} paths {st['paths_ms']:7.2f} | sum {acc.sum().item():.6e}", flush=True)
+    if os.environ.get("VISITS") == "1":
+        ctx.profile(events=False, count_visits=True)
+        _, sv = ctx.render(w, h, cam, 4, accum=acc)
+        print(f"               nodes/ray {sv['node_visits']/max(sv['rays'],1):.3f} prims/ray {sv['prim_tests']/max(sv['rays'],1):.3f} stack {ctx.info()['stack_entries']}", flush=True)
     ctx.close()
