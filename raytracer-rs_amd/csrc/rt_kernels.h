@@ -11,7 +11,10 @@ constexpr int BLOCK = 256;
 // Live paths are kept in NSHARD independent queues.  A block appends its survivors to the queue it read
 // from with ONE atomic per 256 paths; with a single queue that word saturates (about 90 returning
 // atomics per microsecond on one address) and bounds the whole shade step, with 64 words it does not.
-constexpr int NSHARD = 64;
+#ifndef RT_NSHARD
+#define RT_NSHARD 64
+#endif
+constexpr int NSHARD = RT_NSHARD;
 constexpr int MAX_BLOCKS_PER_SHARD = 512;  // upper bound of any grid; launches use the resident block count
 
 // Wavefront path state, structure of arrays, 56 B per path; element (shard s, i) lives at s*cap_shard + i.
