@@ -2,6 +2,7 @@
 """Strong-scaling rehearsal on ONE GPU: renders each rank's share of the frame (tile % N == rank) one rank
 after the other and reports max-over-ranks time per N, i.e. what N GPUs would take without the exchange.
    python scripts/scaling_probe.py [workload] [steps]
+SPP=n overrides the workload's samples per pixel.
 FRAMES_AT_ONCE=1 renders a rank's shares of the step's frames concurrently (one stream and host thread each), as
 bench.py does when the step is split over several ranks.
 """
@@ -22,6 +23,7 @@ workload = sys.argv[1] if len(sys.argv) > 1 else "c2_textures"
 at_once = os.environ.get("FRAMES_AT_ONCE", "0") == "1"  # as bench.py does for N > 1
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 frames_cfg, width, aspect, spp = bench.WORKLOADS[workload]
+spp = int(os.environ.get("SPP", spp))  # (a smaller sample count makes every rank's launches small)
 t1 = None
 for n in (1, 2, 4, 8):
     worst = 0.0
