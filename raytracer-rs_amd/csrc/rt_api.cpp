@@ -95,6 +95,7 @@ struct rt_ctx {
     int bvh_width = -1;  // children per inner node the kernels walk: 2, 4 (four-child form made at commit), -1 by tree size
     uint64_t wide_min_nodes = 1u << 16;  // bvh_width -1: trees of at least this many nodes (4 MiB, one XCD's L2) are walked four-wide
     DevBuf d_wide;
+    bool settle_ahead = true;  // k_shade may settle the first medium's answer for the ray it makes (RTAMD_SETTLE_AHEAD=0: never)
     uint64_t tail_paths = 256u << 10;  // a batch with at most this many live paths is finished by one k_finish launch
     rtk::SpillArea trace_spill;  // deep traversal-stack entries of k_trace (launch_trace grows it)
     // A wave's 64 camera rays are 64 >> this neighbouring pixels x 1 << this samples of each (env RTAMD_SLOT_SAMPLES_LOG2).
@@ -113,7 +114,7 @@ struct rt_ctx {
     uint64_t deal_key[4] = {0, 0, 0, 0};
     uint64_t deal_block_pixels = 0;  // pixels of the largest rank's share (every rank's block is padded to it)
     unsigned char* noalloc_scratch = nullptr;  // this device's copy of the static scratch array (rt_intersect_batch_noalloc)
-    uint32_t* h_counts = nullptr;  // pinned: NSHARD queue counts, then the overflow flag
+    uint32_t* h_counts = nullptr;  // pinned: NSHARD queue counts, the overflow flag (+15 spare), NSHARD counts of settled paths
     unsigned long long* h_rays = nullptr;
 
     // profiling
@@ -344,7 +345,7 @@ int alloc_wavefront(rt_ctx* c, uint64_t cap, bool need_hits) {
             if ((rc = ensure(c, c->d_state[s][3], total * sizeof(uint2)))) return rc;
         }
         if ((rc = ensure(c, c->d_radiance, cap * sizeof(float4)))) return rc;
-        if ((rc = ensure(c, c->d_counts, 3 * rtk::NSHARD * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, c->d_counts, 6 * rtk::NSHARD * sizeof(uint32_t)))) return rc;  // (rows 3..5: the settled paths, rtk::Queues)
         if ((rc = ensure(c, c->d_rays, 128))) return rc;
         if ((rc = ensure(c, c->d_overflow, 16))) return rc;
         c->capacity = cap;
@@ -428,7 +429,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
         return RT_ERR_HIP;
     }
     c->stream = c->own_stream;
-    if (hipHostMalloc((void**)&c->h_counts, (rtk::NSHARD + 16) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void**)&c->h_counts, (2 * rtk::NSHARD + 32) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->h_rays, 128, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return RT_ERR_HIP;
@@ -449,6 +450,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (getenv("RTAMD_SPLIT_MIN_NODE_MB")) c->split_min_node_bytes = (uint64_t)env_u32("RTAMD_SPLIT_MIN_NODE_MB", 256) << 20;
     if (getenv("RTAMD_WHOLE_PATHS")) c->whole_paths_auto = env_u32("RTAMD_WHOLE_PATHS", 1) != 0;
     if (getenv("RTAMD_TAIL_PATHS")) c->tail_paths = env_u32("RTAMD_TAIL_PATHS", 0);
+    c->settle_ahead = env_u32("RTAMD_SETTLE_AHEAD", 1) != 0;
     if (getenv("RTAMD_SLOT_SAMPLES_LOG2")) c->slot_samples_log2 = std::min(env_u32("RTAMD_SLOT_SAMPLES_LOG2", 0), 6u);
     if (getenv("RTAMD_BUILDER")) c->builder = (int)std::min(env_u32("RTAMD_BUILDER", 0), 1u);
     if (getenv("RTAMD_GPU_BUILD_MIN")) c->gpu_build_min = env_u32("RTAMD_GPU_BUILD_MIN", 0);
@@ -834,6 +836,8 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
                               (c->builder == 1 || (c->builder < 0 && world.size() >= c->gpu_build_min));
     auto ttree = std::chrono::steady_clock::now();
     rtb::Result top_r;
+    std::vector<uint32_t> near0;
+    bool near0_known = false, near0_ball = false;
     uint32_t lbvh_depth = 0;
     uint64_t n_nodes_total = 0;
     int rc;
@@ -848,6 +852,43 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         std::vector<uint32_t> order;
         top_r = rtb::build(top, leaf_max, false, base, nodes, order);
         for (uint32_t oi : order) prims.push_back(make_prim(c, world[oi], moving));
+        // the world primitives near the first medium (rtd::Scene::near0_n), by their place in leaf order
+        if (!flat_ok && !nested && !media_groups.empty() && env_u32("RTAMD_NEAR_LIST", 1)) {
+            const rtd::Group& M0 = dgroups[media_groups[0]];
+            // a boundary that is one resting sphere: what matters is the (slightly larger) ball, not its box
+            const auto& bmem = members[media_groups[0] + 1];
+            const bool ball = bmem.size() == 1 && bmem[0].sphere && !(!c->sph.moving.empty() && c->sph.moving[bmem[0].idx]);
+            float bc[3] = {0, 0, 0}, br = 0;
+            if (ball) {
+                const float* a = &c->sph.c0r[4 * (size_t)bmem[0].idx];
+                for (int k = 0; k < 3; k++) bc[k] = a[k];
+                br = std::fabs(a[3]) * 1.001f;
+            }
+            auto meets = [&](const float lo[3], const float hi[3]) {
+                for (int k = 0; k < 3; k++)
+                    if (!(lo[k] <= M0.bhi[k] && hi[k] >= M0.blo[k])) return false;
+                if (ball) {
+                    double d2 = 0;
+                    for (int k = 0; k < 3; k++) {
+                        const double d = bc[k] < lo[k] ? lo[k] - bc[k] : (bc[k] > hi[k] ? bc[k] - hi[k] : 0.0);
+                        d2 += d * d;
+                    }
+                    return d2 <= (double)br * br;
+                }
+                return true;
+            };
+            bool known = !M0.has_xform && M0.parent < 0;
+            for (const rtb::Item& it : top)
+                if (it.type == rtd::REF_INSTANCE && meets(it.lo, it.hi)) known = false;  // an instance reaches into the boundary
+            for (size_t k = 0; known && k < order.size(); k++) {
+                float lo[3], hi[3];
+                prim_box(world[order[k]], lo, hi);
+                if (meets(lo, hi)) near0.push_back(base + (uint32_t)k);
+                if (near0.size() > 32) known = false;
+            }
+            near0_known = known;
+            near0_ball = known && ball;
+        }
         if ((rc = upload(c, c->d_prims, prims.data(), prims.size() * sizeof(rtd::Prim)))) return rc;
         if ((rc = upload(c, c->d_moving, moving.data(), moving.size() * sizeof(rtd::Moving)))) return rc;
         if ((rc = upload(c, c->d_nodes, nodes.data(), nodes.size() * sizeof(rtd::Node)))) return rc;
@@ -988,7 +1029,11 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
 
     // upload
     if ((rc = upload(c, c->d_groups, dgroups.data(), dgroups.size() * sizeof(rtd::Group)))) return rc;
-    if ((rc = upload(c, c->d_media, media_groups.data(), media_groups.size() * sizeof(uint32_t)))) return rc;
+    {
+        std::vector<uint32_t> media_words(media_groups);  // media[], then the primitives near the first medium
+        if (near0_known) media_words.insert(media_words.end(), near0.begin(), near0.end());
+        if ((rc = upload(c, c->d_media, media_words.data(), media_words.size() * sizeof(uint32_t)))) return rc;
+    }
     static_assert(sizeof(rt_material) == sizeof(rtd::Material), "material layout");
     static_assert(sizeof(rt_texture) == sizeof(rtd::Texture), "texture layout");
     // Device material records: a SolidColor texture is folded into the record (one dependent fetch less per
@@ -1065,6 +1110,8 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     // media[] holds only the media that have a boundary: a ConstantMedium around nothing can never be hit, so it
     // is not evaluated (its Group::order still counts it, which keeps the other media's RNG salts where they were)
     S.n_media = (uint32_t)media_groups.size();
+    S.near0_n = near0_known ? (uint32_t)near0.size() : rtd::NEAR_NONE;
+    S.near0_ball = near0_ball ? 1u : 0u;
     S.flat = flat_ok ? 1u : 0u;
     S.nested = nested ? 1u : 0u;
     S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
@@ -1591,8 +1638,9 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                     continue;
                 }
                 if (mode != 0) {
-                    HIP_TRY(c, hipMemsetAsync(q.counts, 0, 3 * rtk::NSHARD * sizeof(uint32_t), c->stream));
+                    HIP_TRY(c, hipMemsetAsync(q.counts, 0, 6 * rtk::NSHARD * sizeof(uint32_t), c->stream));
                 } else {
+                    HIP_TRY(c, hipMemsetAsync(q.counts + 3 * rtk::NSHARD, 0, 3 * rtk::NSHARD * sizeof(uint32_t), c->stream));
                     ScopedTimer tm(c, KS_RAYGEN);
                     HIP_TRY(c, rtk::launch_raygen(c->stream, rcst, batch, path_state(c, 0), q));
                 }
@@ -1608,7 +1656,8 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                         }
                         {
                             ScopedTimer tm(c, KS_SHADE);
-                            HIP_TRY(c, rtk::launch_shade(c->stream, c->scene, rcst, in, out, (const float4*)c->d_hits.p, q, b, bps, d_rad));
+                            HIP_TRY(c, rtk::launch_shade(c->stream, c->scene, rcst, in, out, (const float4*)c->d_hits.p, q, b, bps, d_rad, d_stats,
+                                                         !c->count_visits && c->settle_ahead));
                         }
                     }
                     st.bounce_launches++;
@@ -1617,12 +1666,18 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                     if (check && b + 1 < p->max_depth) {
                         HIP_TRY(c, hipMemcpyAsync(c->h_counts, q.counts + ((b + 1) % 3) * rtk::NSHARD, rtk::NSHARD * sizeof(uint32_t),
                                                   hipMemcpyDeviceToHost, c->stream));
+                        uint32_t* h_settled = c->h_counts + rtk::NSHARD + 16;
+                        if (!fused)
+                            HIP_TRY(c, hipMemcpyAsync(h_settled, q.counts + (3 + (b + 1) % 3) * rtk::NSHARD, rtk::NSHARD * sizeof(uint32_t),
+                                                      hipMemcpyDeviceToHost, c->stream));
                         HIP_TRY(c, hipStreamSynchronize(c->stream));
                         uint32_t longest = 0;
                         uint64_t live = 0;
                         for (int k = 0; k < rtk::NSHARD; k++) {
-                            longest = std::max(longest, c->h_counts[k]);
-                            live += c->h_counts[k];
+                            // (a shard's queue holds its settled paths at the far end; the shade kernel tiles both parts)
+                            const uint32_t both = c->h_counts[k] + (fused ? 0u : h_settled[k] + (h_settled[k] ? (uint32_t)rtk::BLOCK : 0u));
+                            longest = std::max(longest, both);
+                            live += c->h_counts[k] + (fused ? 0u : h_settled[k]);
                         }
                         if (longest == 0) break;
                         bps = (longest + rtk::BLOCK - 1) / rtk::BLOCK;

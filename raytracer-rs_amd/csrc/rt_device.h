@@ -145,6 +145,12 @@ struct Scene {
     // texture records in LDS (n_prims, n_mats, n_texs records of 32 bytes each)
     uint32_t lds_scene, n_mats, n_texs;
     uint32_t nested;  // != 0: some instance stands inside another one (Group::parent >= 0 somewhere)
+    // The surfaces that can be met inside the first medium: indices (into prims[]) of the world primitives whose box meets
+    // that medium's boundary, stored behind media[].  NEAR_NONE: not known (an instance reaches into the boundary's box,
+    // the boundary is transformed, the world's tree was built on the device, more than 32 such primitives).
+    uint32_t near0_n;
+    uint32_t near0_ball;  // != 0: that boundary is one resting sphere, and the list was made for the ball 1.001 times its radius
 };
+constexpr uint32_t NEAR_NONE = 0xFFFFFFFFu;
 
 }  // namespace rtd

@@ -21,12 +21,14 @@ constexpr int MAX_BLOCKS_PER_SHARD = 512;  // upper bound of any grid; launches 
 struct PathState {
     float4* o_time;    // origin.xyz, time
     float4* d_slot;    // direction.xyz, bits(slot)
-    float4* thr_meta;  // throughput.xyz, spare word
+    float4* thr_meta;  // throughput.xyz, distance at which the first medium takes the ray if that is settled already (else 0)
     uint2* key;        // RNG stream key (k0, k1)
 };
 
-// counts: 3 x NSHARD words.  Bounce b reads counts[b % 3], appends to counts[(b + 1) % 3] and clears
-// counts[(b + 2) % 3] for the bounce after it.
+// counts: 6 x NSHARD words.  Bounce b reads counts[b % 3], appends to counts[(b + 1) % 3] and clears
+// counts[(b + 2) % 3] for the bounce after it.  Rows 3..5 count, in the same rotation, the paths k_shade has queued
+// at the far end of each shard (entry cap_shard - 1 - i): their next hit is settled already and the trace kernel
+// passes them by.
 struct Queues {
     uint32_t* counts;
     uint32_t cap_shard;  // entries per shard, multiple of BLOCK
@@ -78,7 +80,8 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& sc
                         uint32_t bounce, uint32_t blocks_per_shard, float4* hits, unsigned long long* stats,
                         uint32_t* overflow_flag, SpillArea& spill);
 hipError_t launch_shade(hipStream_t s, const rtd::Scene& scene, const RenderConst& rc, PathState in, PathState out,
-                        const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance);
+                        const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
+                        unsigned long long* stats, bool may_settle);
 // ---- fused pipeline: one kernel per bounce (bounce 0 generates its camera rays itself) ---------------------
 hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc,
                          const Batch& batch, PathState in, PathState out, Queues q, uint32_t bounce,

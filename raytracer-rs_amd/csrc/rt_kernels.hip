@@ -37,6 +37,9 @@ struct PathRegs {
     f3 o, d, T;
     float time;
     uint32_t k0, k1, slot;  // every path of one launch is at the same bounce, so the bounce is not stored
+    // > 0: the distance at which the first medium takes this ray, found out by the k_shade that made the ray ("settled
+    // ahead", see there).  Such a path waits at the far end of its queue, where the trace kernel does not look.
+    float settled = 0.0f;
 };
 
 // Jitter + Camera::get_ray for path slot `slot` of the batch (main.rs:471-474, camera.rs:54-65).
@@ -104,11 +107,12 @@ DEV void load_path(const rtk::PathState& st, uint32_t idx, PathRegs& p) {
     p.T = {tm.x, tm.y, tm.z};
     p.k0 = key.x;
     p.k1 = key.y;
+    p.settled = tm.w;
 }
 DEV void store_path(const rtk::PathState& st, uint32_t idx, const PathRegs& p) {
     st.o_time[idx] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
     st.d_slot[idx] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(p.slot));
-    st.thr_meta[idx] = make_float4(p.T.x, p.T.y, p.T.z, 0.0f);
+    st.thr_meta[idx] = make_float4(p.T.x, p.T.y, p.T.z, p.settled);
     st.key[idx] = make_uint2(p.k0, p.k1);
 }
 
@@ -167,6 +171,8 @@ DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderCons
 struct CompactLds {
     uint32_t wave_tot[2][rtk::BLOCK / 64];
     uint32_t block_base[2];
+    uint32_t wave_tot_b[2][rtk::BLOCK / 64];  // compact_store2: the second destination
+    uint32_t block_base_b[2];
 };
 DEV void compact_store(CompactLds& lds, uint32_t parity, bool alive, const PathRegs& p, const rtk::PathState& out,
                        uint32_t* out_count, uint32_t shard_base) {
@@ -185,6 +191,38 @@ DEV void compact_store(CompactLds& lds, uint32_t parity, bool alive, const PathR
         uint32_t off = lds.block_base[parity] + prefix;
         for (uint32_t w = 0; w < wave; w++) off += lds.wave_tot[parity][w];
         store_path(out, shard_base + off, p);
+    }
+}
+
+// compact_store with two destinations: survivors of class A are appended to the shard's queue from its start (out_a
+// counts them), those of class B from its far end downwards (out_b): a path is in one of the two, so they never meet.
+DEV void compact_store2(CompactLds& lds, uint32_t parity, bool a, bool b, const PathRegs& p, const rtk::PathState& out,
+                        uint32_t* out_a, uint32_t* out_b, uint32_t shard_base, uint32_t cap_shard) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mask_a = __ballot(a), mask_b = __ballot(b);
+    if (lane == 0) {
+        lds.wave_tot[parity][wave] = (uint32_t)__popcll(mask_a);
+        lds.wave_tot_b[parity][wave] = (uint32_t)__popcll(mask_b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot_a = 0, tot_b = 0;
+        for (int w = 0; w < rtk::BLOCK / 64; w++) {
+            tot_a += lds.wave_tot[parity][w];
+            tot_b += lds.wave_tot_b[parity][w];
+        }
+        lds.block_base[parity] = tot_a ? atomicAdd(out_a, tot_a) : 0u;
+        lds.block_base_b[parity] = tot_b ? atomicAdd(out_b, tot_b) : 0u;
+    }
+    __syncthreads();
+    if (a) {
+        uint32_t off = lds.block_base[parity] + lane_prefix(mask_a);
+        for (uint32_t w = 0; w < wave; w++) off += lds.wave_tot[parity][w];
+        store_path(out, shard_base + off, p);
+    } else if (b) {
+        uint32_t off = lds.block_base_b[parity] + lane_prefix(mask_b);
+        for (uint32_t w = 0; w < wave; w++) off += lds.wave_tot_b[parity][w];
+        store_path(out, shard_base + cap_shard - 1u - off, p);
     }
 }
 
@@ -448,36 +486,117 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
     }
 }
 
-template <bool NESTED>
+// Settled ahead.  A path that has just scattered in the first medium will most likely scatter there again a few units on:
+// final_scene's blue sphere (main.rs:281-284: mean free path 5 in a radius of 70, nothing absorbed) holds 5 % of the paths
+// for all 50 bounces, a third of the frame's rays.  While such a ray starts inside the boundary, the only surfaces it can
+// meet before it leaves are the few whose box meets the boundary (Scene::near0_n, found at commit), and the medium sees
+// surfaces only through min(r2, t) with r2 on the boundary.  So k_shade tests the ray it has just made against those
+// primitives and then lets the first medium decide, exactly as the next bounce would after the tree walk: if the medium
+// takes the ray, that IS the next bounce's answer for this medium; the distance travels with the path, and the path
+// is queued at the far end of its shard (a second count per shard, rtk::Queues), where the trace kernel does not look.
+// The next k_shade takes those paths as tiles of their own, with the hit made from the stored distance and the media
+// starting at the second one.  If the medium does not take the ray (it leaves, or meets a surface), nothing is settled
+// and the ray goes through the tree as usual.  Paths join when at least `entry_lanes` lanes of their wave qualify (the
+// test costs the wave the same for one lane as for 64); a tile of settled paths tests all of its own.
+// SETTLE: compiled with that (launched for scenes whose first medium has a known near list); without it the plain loop.
+template <bool NESTED, bool SETTLE>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
                                                        const float4* __restrict__ hits, rtk::Queues q, uint32_t bounce,
-                                                       float4* __restrict__ radiance) {
+                                                       float4* __restrict__ radiance, unsigned long long* stats, uint32_t entry_lanes) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // no traversal here: only the staged tables (launched with stack_cap = 0 in mind)
     __shared__ CompactLds clds;
     Scene St = S;
     St.stack_cap = 0;
     const LdsTables L = stage_tables(St, stack);
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
-    const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
-    uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
-    const uint32_t shard_base = shard * q.cap_shard;
-    uint32_t parity = 0;
-    for (uint32_t base = j0 * rtk::BLOCK; base < n; base += stride * rtk::BLOCK, parity ^= 1u) {
-        const uint32_t i = base + threadIdx.x;
-        bool alive = false;
-        PathRegs p;
-        if (i < n) {
-            load_path(in, shard_base + i, p);
-            float4 hv = hits[shard_base + i];
-            Hit h;
-            h.t = hv.x;
-            h.prim = __float_as_uint(hv.y);
-            h.grp = __float_as_int(hv.z);
-            h.key = __float_as_uint(hv.w);
-            if (S.n_media) apply_media<false, NESTED>(S, p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h, nullptr);
-            alive = shade_path<NESTED>(S, L, rc, p, h, bounce, radiance);
+    if (!SETTLE) {
+        const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
+        uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
+        const uint32_t shard_base = shard * q.cap_shard;
+        uint32_t parity = 0;
+        for (uint32_t base = j0 * rtk::BLOCK; base < n; base += stride * rtk::BLOCK, parity ^= 1u) {
+            const uint32_t i = base + threadIdx.x;
+            bool alive = false;
+            PathRegs p;
+            if (i < n) {
+                load_path(in, shard_base + i, p);
+                float4 hv = hits[shard_base + i];
+                Hit h;
+                h.t = hv.x;
+                h.prim = __float_as_uint(hv.y);
+                h.grp = __float_as_int(hv.z);
+                h.key = __float_as_uint(hv.w);
+                if (S.n_media) apply_media<false, NESTED>(S, p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h, nullptr);
+                alive = shade_path<NESTED>(S, L, rc, p, h, bounce, radiance);
+            }
+            compact_store(clds, parity, alive, p, out, out_count, shard_base);
         }
-        compact_store(clds, parity, alive, p, out, out_count, shard_base);
+        return;
+    }
+    const bool settle = true;
+    const uint32_t medium0 = settle ? (HIT_MEDIUM_BIT | S.media[0]) : 0u;
+    const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
+    const uint32_t n_settled = q.counts[(3u + bounce % 3u) * rtk::NSHARD + shard];
+    uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
+    uint32_t* out_settled = q.counts + (3u + (bounce + 1u) % 3u) * rtk::NSHARD + shard;
+    const uint32_t shard_base = shard * q.cap_shard;
+    if (j0 == 0 && threadIdx.x == 0) {
+        q.counts[(3u + (bounce + 2u) % 3u) * rtk::NSHARD + shard] = 0;  // the next bounce appends there
+        if (n_settled) atomicAdd(stats, (unsigned long long)n_settled);  // rays that never saw the trace kernel
+    }
+    const uint32_t tiles = (n + rtk::BLOCK - 1u) / rtk::BLOCK, tiles_settled = (n_settled + rtk::BLOCK - 1u) / rtk::BLOCK;
+    uint32_t parity = 0;
+    for (uint32_t tile = j0; tile < tiles + tiles_settled; tile += stride, parity ^= 1u) {
+        const bool settled_tile = tile >= tiles;  // (the same for the whole block)
+        const uint32_t i = (settled_tile ? tile - tiles : tile) * rtk::BLOCK + threadIdx.x;
+        const uint32_t at = shard_base + (settled_tile ? q.cap_shard - 1u - i : i);
+        bool alive = false, candidate = false;
+        PathRegs p;
+        if (i < (settled_tile ? n_settled : n)) {
+            load_path(in, at, p);
+            Hit h;
+            if (settled_tile) {
+                h.t = p.settled;
+                h.prim = medium0;
+                h.grp = -1;
+                h.key = 0;
+            } else {
+                float4 hv = hits[at];
+                h.t = hv.x;
+                h.prim = __float_as_uint(hv.y);
+                h.grp = __float_as_int(hv.z);
+                h.key = __float_as_uint(hv.w);
+            }
+            p.settled = 0.0f;
+            for (uint32_t m = settled_tile ? 1u : 0u; m < S.n_media; m++)
+                test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h);
+            alive = shade_path<NESTED>(S, L, rc, p, h, bounce, radiance);
+            candidate = alive && settle && h.prim == medium0;
+        }
+        if (settle && (uint32_t)__popcll(__ballot(candidate)) >= (settled_tile ? 1u : entry_lanes) && candidate) {
+            const Group& G = S.groups[S.media[0]];
+            bool inside = p.o.x >= G.blo[0] && p.o.x <= G.bhi[0] && p.o.y >= G.blo[1] && p.o.y <= G.bhi[1] && p.o.z >= G.blo[2] &&
+                          p.o.z <= G.bhi[2];
+            if (S.near0_ball) {  // (the list holds what meets the ball of 1.001 radii: the origin within 1.0005 of them)
+                const float4 sph = *reinterpret_cast<const float4*>(S.prims + (G.root_ref & 0x03FFFFFFu));
+                const f3 oc = p.o - mk3(sph.x, sph.y, sph.z);
+                const float rr = sph.w * 1.0005f;
+                inside = inside && dot3(oc, oc) <= rr * rr;
+            }
+            if (inside) {
+                Hit nh;
+                nh.t = INF_F;
+                nh.prim = HIT_NONE;
+                nh.grp = -1;
+                nh.key = 0;
+                const float a = dot3(p.d, p.d);
+                for (uint32_t k = 0; k < S.near0_n; k++) test_prim<false>(S, S.media[S.n_media + k], p.o, p.d, a, p.time, 0.005f, -1, nh);
+                test_medium<NESTED>(S, S.media[0], p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce + 1u, nh);
+                if (nh.prim == medium0 && nh.t > 0.0f) p.settled = nh.t;
+            }
+        }
+        compact_store2(clds, parity, alive && !(p.settled > 0.0f), alive && p.settled > 0.0f, p, out, out_count, out_settled, shard_base,
+                       q.cap_shard);
     }
 }
 
@@ -495,10 +614,12 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
     const uint32_t shard_base = shard * q.cap_shard;
     const Stack stk{stack + threadIdx.x, S.stack_cap, nullptr, 0u};
     const LdsTables L = stage_tables(S, stack);
+    // (paths whose next hit k_shade has settled wait at the far end of the queue; here they are walked like the others)
+    const uint32_t n_settled = q.counts[(3u + bounce % 3u) * rtk::NSHARD + shard];
     uint32_t rays = 0;
-    for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
+    for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n + n_settled; i += stride * rtk::BLOCK) {
         PathRegs p;
-        load_path(in, shard_base + i, p);
+        load_path(in, shard_base + (i < n ? i : q.cap_shard - 1u - (i - n)), p);
         for (uint32_t b = bounce;; b++) {  // shade_path ends the path at the depth limit at the latest
             Hit h;
             trace_ray<rtk::BLOCK, GROUPS, FLAT, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, b, h, stk, overflow_flag, nullptr);
@@ -848,14 +969,23 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
 }
 
 hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc, PathState in, PathState out,
-                        const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance) {
+                        const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
+                        unsigned long long* stats, bool may_settle) {
     const size_t smem = table_bytes(scene);
-    if (scene.nested)
-        hipLaunchKernelGGL(k_shade<true>, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<true>, oversubscription(), smem)), dim3(BLOCK), smem, s,
-                           scene, rc, in, out, hits, q, bounce, radiance);
-    else
-        hipLaunchKernelGGL(k_shade<false>, dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<false>, oversubscription(), smem)), dim3(BLOCK), smem, s,
-                           scene, rc, in, out, hits, q, bounce, radiance);
+    // lanes of a wave that have to qualify for its paths to be settled ahead (see k_shade)
+    static const uint32_t entry_lanes = std::min(64u, std::max(1u, getenv("RTAMD_SETTLE_ENTRY") ? (uint32_t)atoi(getenv("RTAMD_SETTLE_ENTRY")) : 8u));
+    const bool settle = may_settle && scene.n_media != 0u && scene.near0_n != NEAR_NONE;
+#define RT_SHADE(N, T)                                                                                                              \
+    hipLaunchKernelGGL((k_shade<N, T>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<N, T>, oversubscription(), smem)), \
+                       dim3(BLOCK), smem, s, scene, rc, in, out, hits, q, bounce, radiance, stats, entry_lanes)
+    if (scene.nested) {
+        if (settle) RT_SHADE(true, true);
+        else RT_SHADE(true, false);
+    } else {
+        if (settle) RT_SHADE(false, true);
+        else RT_SHADE(false, false);
+    }
+#undef RT_SHADE
     return hipGetLastError();
 }
 

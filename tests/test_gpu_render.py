@@ -520,6 +520,30 @@ def test_tail_kernel_changes_no_bit(name):
         assert rays == out[0][1] and np.array_equal(img, out[0][0])
 
 
+@pytest.mark.parametrize("name", ["final_scene", "medium_cluster"])
+def test_settling_the_first_medium_ahead_changes_no_bit(name, monkeypatch):
+    """k_shade may find out for the ray it has just made that the first medium takes it (primitives near the boundary, then
+    the medium's own test) and queue the path where the trace kernel does not look.  The answer is the one the next bounce
+    would have found after the tree walk, so image and ray count must not change: with the paths joining from one lane per
+    wave on, with the default, and with the tail kernel taking over queues that hold such paths."""
+    w, h, spp = 200, 200, 24
+    out = []
+    for settle, entry, tail in (("0", "8", 0), ("1", "1", 0), ("1", "8", 0), ("1", "8", 20000)):
+        monkeypatch.setenv("RTAMD_SETTLE_AHEAD", settle)
+        monkeypatch.setenv("RTAMD_SETTLE_ENTRY", entry)  # (read once per process: the first value stays; the default is covered either way)
+        ctx = rtamd.Context(0)
+        ctx.load_scene(name, seed=1)
+        ctx.set_tail_paths(tail)
+        cam = ctx.preset_camera(w / h)
+        for pipe in (0, 2):
+            ctx.set_pipeline(pipe)
+            img, st = ctx.render(w, h, cam, spp, seed=5)
+            out.append((img, st["rays"]))
+        ctx.close()
+    for img, rays in out[1:]:
+        assert rays == out[0][1] and np.array_equal(img, out[0][0])
+
+
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "two_spheres", "simple_light"])
 def test_flat_and_tree_tracing_give_the_same_bits(name, monkeypatch):
     """Scenes of a few dozen primitives are traced without the tree (uniform loops over the primitives).  The
