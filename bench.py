@@ -315,7 +315,9 @@ def kernel_rooflines(frames, stats, steps, workload, use_committed, width=0, spp
             bo_bytes += fused_rays * bounce_bytes_per_ray(f.info, primary, alive, nodes_pr, prims_pr)
             bo_bytes += scene_bytes_per_launch(f.info) * sum(s["bounce_kernel_launches"] for s in st_frame)
         if split_rays:
-            tr_bytes += split_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
+            # (rays settled by the bounce before them go from k_shade to k_shade: the trace kernel never reads them)
+            walked_rays = split_rays - sum(s.get("settled_rays", 0) for s in st_frame)
+            tr_bytes += walked_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
             tr_bytes += scene_bytes_per_launch(f.info) * sum(s["trace_launches"] for s in st_frame)
             sh_bytes += split_rays * shade_bytes_per_ray(alive)
     launches = {k: sum(st[k] for s in stats for st in s) for k in ("trace_launches", "shade_launches", "bounce_kernel_launches", "paths_launches")}

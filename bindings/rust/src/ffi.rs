@@ -131,6 +131,7 @@ pub struct rt_render_stats {
     pub tail_ms: f64,
     pub paths_ms: f64,
     pub paths_launches: u64,
+    pub settled_rays: u64,
 }
 
 extern "C" {

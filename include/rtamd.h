@@ -255,6 +255,7 @@ typedef struct rt_render_stats {
     double tail_ms;       /* HIP-event time of the tail kernel (profile flag 1) */
     double paths_ms;      /* pipeline 3: HIP-event time of the whole-path kernel (profile flag 1) */
     uint64_t paths_launches;
+    uint64_t settled_rays; /* rays whose hit in the first medium was found by the bounce before them, without the tree walk (included in rays) */
 } rt_render_stats;
 
 int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* accum_rgb,

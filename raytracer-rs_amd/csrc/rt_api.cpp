@@ -346,7 +346,7 @@ int alloc_wavefront(rt_ctx* c, uint64_t cap, bool need_hits) {
         }
         if ((rc = ensure(c, c->d_radiance, cap * sizeof(float4)))) return rc;
         if ((rc = ensure(c, c->d_counts, 6 * rtk::NSHARD * sizeof(uint32_t)))) return rc;  // (rows 3..5: the settled paths, rtk::Queues)
-        if ((rc = ensure(c, c->d_rays, 128))) return rc;
+        if ((rc = ensure(c, c->d_rays, 256))) return rc;
         if ((rc = ensure(c, c->d_overflow, 16))) return rc;
         c->capacity = cap;
         c->cap_shard = (uint32_t)cap_shard;
@@ -430,7 +430,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     }
     c->stream = c->own_stream;
     if (hipHostMalloc((void**)&c->h_counts, (2 * rtk::NSHARD + 32) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_rays, 128, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_rays, 256, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return RT_ERR_HIP;
     }
@@ -1603,7 +1603,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     st.pipeline = (uint32_t)mode;
     if (n_owned && n_samples_total) {
         if ((rc = reserve_paths(c, n_owned * (uint64_t)n_samples_total, !fused))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 128, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_rays.p, 0, 256, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
         const rtk::Queues q{(uint32_t*)c->d_counts.p, c->cap_shard};
         const rtk::TraceCfg tcfg{c->stack_entries, c->has_groups, c->count_visits, c->scene.nested != 0u};
@@ -1699,13 +1699,14 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 }
             }
         }
-        HIP_TRY(c, hipMemcpyAsync(c->h_rays, c->d_rays.p, 128, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_rays, c->d_rays.p, 256, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_counts + rtk::NSHARD, c->d_overflow.p, 4, hipMemcpyDeviceToHost, c->stream));
     }
     if (!accum_dev) HIP_TRY(c, hipMemcpyAsync(accum_rgb, d_accum, accum_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_owned && n_samples_total) {
         st.tail_rays = c->h_rays[8];
+        st.settled_rays = c->h_rays[16];
         st.rays = c->h_rays[0] + st.tail_rays;
         st.node_visits = c->h_rays[1];
         st.prim_tests = c->h_rays[2];

@@ -67,7 +67,7 @@ struct TraceCfg {
 
 // stats: 64-bit words: [0] += rays traced by the per-bounce kernels; with count_visits also [1] += inner nodes
 // fetched, [2] += primitive records tested ([3..7]: section cycles of the instrumented fused kernel);
-// [8] += rays traced by the tail kernel.
+// [8] += rays traced by the tail kernel; [16] += rays k_shade took from the settled end of the queues (also in [0]).
 
 // ---- split pipeline: raygen, then per bounce trace + shade --------------------------------------------
 hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q);

@@ -542,7 +542,10 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
     const uint32_t shard_base = shard * q.cap_shard;
     if (j0 == 0 && threadIdx.x == 0) {
         q.counts[(3u + (bounce + 2u) % 3u) * rtk::NSHARD + shard] = 0;  // the next bounce appends there
-        if (n_settled) atomicAdd(stats, (unsigned long long)n_settled);  // rays that never saw the trace kernel
+        if (n_settled) {  // rays that never saw the trace kernel
+            atomicAdd(stats, (unsigned long long)n_settled);
+            atomicAdd(stats + 16, (unsigned long long)n_settled);
+        }
     }
     const uint32_t tiles = (n + rtk::BLOCK - 1u) / rtk::BLOCK, tiles_settled = (n_settled + rtk::BLOCK - 1u) / rtk::BLOCK;
     uint32_t parity = 0;

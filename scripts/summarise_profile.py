@@ -26,13 +26,13 @@ def stats(path, out, title, command):
     lines = ["# %s" % title, "", "Command (on the MI355X box): `%s`" % command, "",
              "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     # all template instances of one kernel together (bench.py times them as one kernel), without the instrumented
-    # instances (second template argument true) that bench.py only runs in its untimed counting pass
+    # instances (k_trace / k_bounce / k_intersect_batch with the second template argument true) that bench.py only runs in its untimed counting pass
     fams = {}
     for r in rows:
         name = short(r["Name"])
         if name.startswith("k_") and "<" in name:
             args = name[name.index("<") + 1:].rstrip(">").split(",")
-            if len(args) > 1 and args[1].strip() == "true":
+            if name[:name.index("<")] in ("k_trace", "k_bounce", "k_intersect_batch") and len(args) > 1 and args[1].strip() == "true":
                 continue
             f = fams.setdefault(name[:name.index("<")], [0, 0.0])
             f[0] += int(r["Calls"])

@@ -538,6 +538,8 @@ def test_settling_the_first_medium_ahead_changes_no_bit(name, monkeypatch):
         for pipe in (0, 2):
             ctx.set_pipeline(pipe)
             img, st = ctx.render(w, h, cam, spp, seed=5)
+            if name == "final_scene":  # (its first medium is the dense sphere that holds paths for many bounces)
+                assert (st["settled_rays"] > 0.1 * st["rays"]) if settle == "1" else st["settled_rays"] == 0
             out.append((img, st["rays"]))
         ctx.close()
     for img, rays in out[1:]:
