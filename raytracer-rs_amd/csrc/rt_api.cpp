@@ -95,6 +95,7 @@ struct rt_ctx {
     int bvh_width = -1;  // children per inner node the kernels walk: 2, 4 (four-child form made at commit), -1 by tree size
     uint64_t wide_min_nodes = 1u << 16;  // bvh_width -1: trees of at least this many nodes (4 MiB, one XCD's L2) are walked four-wide
     DevBuf d_wide;
+    bool debug_live = false;
     bool settle_ahead = true;  // k_shade may settle the first medium's answer for the ray it makes (RTAMD_SETTLE_AHEAD=0: never)
     uint64_t tail_paths = 256u << 10;  // a batch with at most this many live paths is finished by one k_finish launch
     rtk::SpillArea trace_spill;  // deep traversal-stack entries of k_trace (launch_trace grows it)
@@ -451,6 +452,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     if (getenv("RTAMD_WHOLE_PATHS")) c->whole_paths_auto = env_u32("RTAMD_WHOLE_PATHS", 1) != 0;
     if (getenv("RTAMD_TAIL_PATHS")) c->tail_paths = env_u32("RTAMD_TAIL_PATHS", 0);
     c->settle_ahead = env_u32("RTAMD_SETTLE_AHEAD", 1) != 0;
+    c->debug_live = env_u32("RTAMD_DEBUG_LIVE", 0) != 0;
     if (getenv("RTAMD_SLOT_SAMPLES_LOG2")) c->slot_samples_log2 = std::min(env_u32("RTAMD_SLOT_SAMPLES_LOG2", 0), 6u);
     if (getenv("RTAMD_BUILDER")) c->builder = (int)std::min(env_u32("RTAMD_BUILDER", 0), 1u);
     if (getenv("RTAMD_GPU_BUILD_MIN")) c->gpu_build_min = env_u32("RTAMD_GPU_BUILD_MIN", 0);
@@ -1679,6 +1681,12 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                             longest = std::max(longest, both);
                             live += c->h_counts[k] + (fused ? 0u : h_settled[k]);
                         }
+                        if (c->debug_live) {  // RTAMD_DEBUG_LIVE=1: paths alive after each checked bounce (front of the queues / settled end)
+                            uint64_t settled = 0;
+                            for (int k = 0; k < rtk::NSHARD && !fused; k++) settled += h_settled[k];
+                            fprintf(stderr, "[rtamd] after bounce %u: %llu paths alive, %llu of them settled ahead\n", b, (unsigned long long)live,
+                                    (unsigned long long)settled);
+                        }
                         if (longest == 0) break;
                         bps = (longest + rtk::BLOCK - 1) / rtk::BLOCK;
                         if (live <= c->tail_paths && !c->count_visits) {
@@ -1707,6 +1715,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (n_owned && n_samples_total) {
         st.tail_rays = c->h_rays[8];
         st.settled_rays = c->h_rays[16];
+        if (getenv("RTAMD_HIST")) { fprintf(stderr, "[rtamd] hist:"); for (int k = 17; k < 32; k++) fprintf(stderr, " %llu", c->h_rays[k]); fprintf(stderr, "\n"); }
         st.rays = c->h_rays[0] + st.tail_rays;
         st.node_visits = c->h_rays[1];
         st.prim_tests = c->h_rays[2];

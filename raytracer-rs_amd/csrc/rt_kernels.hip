@@ -573,6 +573,17 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             p.settled = 0.0f;
             for (uint32_t m = settled_tile ? 1u : 0u; m < S.n_media; m++)
                 test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h);
+#ifdef RT_HIST
+            if (!settled_tile && bounce >= 16u) {
+                uint32_t cls = 4u;
+                if (h.prim == HIT_NONE) cls = 0u;
+                else if (h.prim == medium0) cls = 1u;
+                else if (h.prim & HIT_MEDIUM_BIT) cls = 2u;
+                else { for (uint32_t k = 0; k < S.near0_n; k++) if (h.prim == S.media[S.n_media + k]) cls = 3u; }
+                if (cls == 4u) { float4 A, B; load_record(L, L.prims, S.prims, h.prim, A, B); const Material M = load_material(S, L, __float_as_uint(B.y) >> 8); cls = 4u + M.kind; if (h.grp >= 0) cls = 10u; }
+                atomicAdd(stats + 17 + cls, 1ull);
+            }
+#endif
             alive = shade_path<NESTED>(S, L, rc, p, h, bounce, radiance);
             candidate = alive && settle && h.prim == medium0;
         }
