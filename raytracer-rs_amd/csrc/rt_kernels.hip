@@ -37,8 +37,9 @@ struct PathRegs {
     f3 o, d, T;
     float time;
     uint32_t k0, k1, slot;  // every path of one launch is at the same bounce, so the bounce is not stored
-    // > 0: the distance at which the first medium takes this ray, found out by the k_shade that made the ray ("settled
-    // ahead", see there).  Such a path waits at the far end of its queue, where the trace kernel does not look.
+    // != 0: the hit of this ray, found out by the k_shade that made the ray ("settled ahead", see there): > 0 the distance at
+    // which the first medium takes it, < 0 minus the distance at which it meets the one primitive near that medium.  Such
+    // a path waits at the far end of its queue, where the trace kernel does not look.
     float settled = 0.0f;
 };
 
@@ -502,7 +503,8 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
 template <bool NESTED, bool SETTLE>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
                                                        const float4* __restrict__ hits, rtk::Queues q, uint32_t bounce,
-                                                       float4* __restrict__ radiance, unsigned long long* stats, uint32_t entry_lanes) {
+                                                       float4* __restrict__ radiance, unsigned long long* stats, uint32_t entry_lanes,
+                                                       uint32_t near_hits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // no traversal here: only the staged tables (launched with stack_cap = 0 in mind)
     __shared__ CompactLds clds;
     Scene St = S;
@@ -535,6 +537,8 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
     }
     const bool settle = true;
     const uint32_t medium0 = settle ? (HIT_MEDIUM_BIT | S.media[0]) : 0u;
+    // the single primitive near a ball-shaped boundary, whose hits from inside can be settled as well (else: no such index)
+    const uint32_t near_prim = (settle && S.near0_ball && S.near0_n == 1u && near_hits) ? S.media[S.n_media] : 0x7FFFFFFFu;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     const uint32_t n_settled = q.counts[(3u + bounce % 3u) * rtk::NSHARD + shard];
     uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
@@ -558,9 +562,9 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
         if (i < (settled_tile ? n_settled : n)) {
             load_path(in, at, p);
             Hit h;
-            if (settled_tile) {
-                h.t = p.settled;
-                h.prim = medium0;
+            if (settled_tile) {  // (> 0: the first medium at that distance; < 0: the one primitive near it)
+                h.t = __builtin_fabsf(p.settled);
+                h.prim = p.settled > 0.0f ? medium0 : near_prim;
                 h.grp = -1;
                 h.key = 0;
             } else {
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             }
 #endif
             alive = shade_path<NESTED>(S, L, rc, p, h, bounce, radiance);
-            candidate = alive && settle && h.prim == medium0;
+            candidate = alive && settle && (h.prim == medium0 || h.prim == near_prim);
         }
         if (settle && (uint32_t)__popcll(__ballot(candidate)) >= (settled_tile ? 1u : entry_lanes) && candidate) {
             const Group& G = S.groups[S.media[0]];
@@ -606,10 +610,20 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
                 const float a = dot3(p.d, p.d);
                 for (uint32_t k = 0; k < S.near0_n; k++) test_prim<false>(S, S.media[S.n_media + k], p.o, p.d, a, p.time, 0.005f, -1, nh);
                 test_medium<NESTED>(S, S.media[0], p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce + 1u, nh);
-                if (nh.prim == medium0 && nh.t > 0.0f) p.settled = nh.t;
+                if (nh.prim == medium0 && nh.t > 0.0f) {
+                    p.settled = nh.t;
+                } else if (nh.prim == near_prim && nh.t > 0.0f) {
+                    // The medium lets the ray pass and it meets the one primitive near the boundary (the glass around the
+                    // medium, from inside).  That is the tree's answer as well if the hit point still lies in the ball: no
+                    // other primitive reaches in there.
+                    const float4 sph = *reinterpret_cast<const float4*>(S.prims + (G.root_ref & 0x03FFFFFFu));
+                    const f3 pc = (p.o + nh.t * p.d) - mk3(sph.x, sph.y, sph.z);
+                    const float rr = sph.w * 1.0005f;
+                    if (dot3(pc, pc) <= rr * rr) p.settled = -nh.t;
+                }
             }
         }
-        compact_store2(clds, parity, alive && !(p.settled > 0.0f), alive && p.settled > 0.0f, p, out, out_count, out_settled, shard_base,
+        compact_store2(clds, parity, alive && p.settled == 0.0f, alive && p.settled != 0.0f, p, out, out_count, out_settled, shard_base,
                        q.cap_shard);
     }
 }
@@ -989,9 +1003,10 @@ hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc
     // lanes of a wave that have to qualify for its paths to be settled ahead (see k_shade)
     static const uint32_t entry_lanes = std::min(64u, std::max(1u, getenv("RTAMD_SETTLE_ENTRY") ? (uint32_t)atoi(getenv("RTAMD_SETTLE_ENTRY")) : 8u));
     const bool settle = may_settle && scene.n_media != 0u && scene.near0_n != NEAR_NONE;
+    static const uint32_t near_hits = getenv("RTAMD_SETTLE_NEAR_HITS") ? (uint32_t)atoi(getenv("RTAMD_SETTLE_NEAR_HITS")) : 1u;
 #define RT_SHADE(N, T)                                                                                                              \
     hipLaunchKernelGGL((k_shade<N, T>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<N, T>, oversubscription(), smem)), \
-                       dim3(BLOCK), smem, s, scene, rc, in, out, hits, q, bounce, radiance, stats, entry_lanes)
+                       dim3(BLOCK), smem, s, scene, rc, in, out, hits, q, bounce, radiance, stats, entry_lanes, near_hits)
     if (scene.nested) {
         if (settle) RT_SHADE(true, true);
         else RT_SHADE(true, false);
