@@ -48,7 +48,7 @@ struct HostImage {
     std::vector<uint8_t> rgb;
 };
 
-enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_BOUNCE = 4, KS_TAIL = 5, KS_PATHS = 6, KS_COUNT = 7 };
+enum KernelSlot { KS_RAYGEN = 0, KS_TRACE = 1, KS_SHADE = 2, KS_ACCUM = 3, KS_BOUNCE = 4, KS_TAIL = 5, KS_PATHS = 6, KS_SETTLED = 7, KS_COUNT = 8 };
 
 }  // namespace
 
@@ -104,7 +104,17 @@ struct rt_ctx {
     // same few surface points and meet the same materials -- against 64 pixels x 1 sample: random_world -4 %, two_spheres
     // -6 %, 10 M spheres -5 %, final_scene -0.6 %, cornell_smoke +1 %; same bits (a path's draws are keyed by pixel and sample).
     uint32_t slot_samples_log2 = 4;
-    DevBuf d_state[2][4], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;
+    DevBuf d_state[2][5], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;  // ([4]: PathState::settled, split pipeline only)
+    // Knobs, all read from the environment once in rt_ctx_create (listed in INTEGRATION.md): launch shapes ...
+    rtk::Tuning tune;
+    // ... and what rt_scene_commit / rt_render consult
+    uint32_t flat_max = 48;      // RTAMD_FLAT_MAX: scenes of at most this many primitives are traced without a tree
+    uint32_t leaf_max = 1;       // RTAMD_LEAF_MAX: primitives per leaf of the host-built trees
+    bool near_list = true;       // RTAMD_NEAR_LIST=0: never make the near list of the first medium (no settling ahead)
+    bool lds_tables = true;      // RTAMD_LDS_TABLES=0: shading kernels read every table from global memory
+    bool print_hist = false;     // RTAMD_HIST (builds with -DRT_HIST): what late unsettled rays hit
+    bool print_sections = false; // RTAMD_SECTION_CYCLES: wave cycles per section of the instrumented fused kernel
+    bool print_trace_lanes = false;  // RTAMD_TRACE_LANES: lane use of the instrumented persistent trace kernel
     uint64_t pixels_key[5] = {0, 0, 0, 0, 0};
     uint64_t n_owned = 0;
     // frame exchange between ranks (rt_comm_*, rt_gather_frame)
@@ -345,6 +355,7 @@ int alloc_wavefront(rt_ctx* c, uint64_t cap, bool need_hits) {
                 if ((rc = ensure(c, c->d_state[s][a], total * sizeof(float4)))) return rc;
             if ((rc = ensure(c, c->d_state[s][3], total * sizeof(uint2)))) return rc;
         }
+        for (int s = 0; s < 2; s++) c->d_state[s][4].release();  // (sized with the hit buffer below)
         if ((rc = ensure(c, c->d_radiance, cap * sizeof(float4)))) return rc;
         if ((rc = ensure(c, c->d_counts, 6 * rtk::NSHARD * sizeof(uint32_t)))) return rc;  // (rows 3..5: the settled paths, rtk::Queues)
         if ((rc = ensure(c, c->d_rays, 256))) return rc;
@@ -352,7 +363,12 @@ int alloc_wavefront(rt_ctx* c, uint64_t cap, bool need_hits) {
         c->capacity = cap;
         c->cap_shard = (uint32_t)cap_shard;
     }
-    if (need_hits && (rc = ensure(c, c->d_hits, (uint64_t)c->cap_shard * rtk::NSHARD * sizeof(float4)))) return rc;
+    if (need_hits) {
+        const uint64_t total = (uint64_t)c->cap_shard * rtk::NSHARD;
+        if ((rc = ensure(c, c->d_hits, total * sizeof(float4)))) return rc;
+        for (int s = 0; s < 2; s++)
+            if ((rc = ensure(c, c->d_state[s][4], total * sizeof(float)))) return rc;
+    }
     return RT_OK;
 }
 rtk::PathState path_state(rt_ctx* c, int s) {
@@ -361,20 +377,21 @@ rtk::PathState path_state(rt_ctx* c, int s) {
     p.d_slot = (float4*)c->d_state[s][1].p;
     p.thr_meta = (float4*)c->d_state[s][2].p;
     p.key = (uint2*)c->d_state[s][3].p;
+    p.settled = (float*)c->d_state[s][4].p;  // (null in the fused pipelines, which never settle)
     return p;
 }
 
 // Wavefront buffers for a render of n_paths camera samples: one batch if it fits, else the largest that does.
 // Large batches amortise the per-bounce launches and tails (one batch of 512 Mi paths renders a 1080p frame at
 // 256 spp ~20% faster than eight of 64 Mi), but they must fit: at most 60% of what the device has free now plus
-// what the wavefront buffers already hold (144 bytes per path).
+// what the wavefront buffers already hold (152 bytes per path).
 int reserve_paths(rt_ctx* c, uint64_t n_paths, bool need_hits) {
     uint64_t cap = std::min<uint64_t>(c->max_paths, n_paths);
     if (cap > c->capacity) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const uint64_t held = c->capacity * 144ull;
-            const uint64_t fit = (uint64_t)(0.6 * (double)(free_b + held)) / 144ull;
+            const uint64_t held = c->capacity * 152ull;
+            const uint64_t fit = (uint64_t)(0.6 * (double)(free_b + held)) / 152ull;
             cap = std::min<uint64_t>(cap, std::max<uint64_t>(fit, 1ull << 20));
         } else {
             (void)hipGetLastError();
@@ -462,6 +479,31 @@ int rt_ctx_create(int device, rt_ctx** out) {
     }
     if (getenv("RTAMD_FUSE_BOXES")) c->fuse_boxes = env_u32("RTAMD_FUSE_BOXES", 1) != 0;
     if (getenv("RTAMD_WIDE_MIN_NODES")) c->wide_min_nodes = env_u32("RTAMD_WIDE_MIN_NODES", 0);
+    c->flat_max = env_u32("RTAMD_FLAT_MAX", c->flat_max);
+    c->leaf_max = env_u32("RTAMD_LEAF_MAX", c->leaf_max);
+    c->near_list = env_u32("RTAMD_NEAR_LIST", 1) != 0;
+    c->lds_tables = env_u32("RTAMD_LDS_TABLES", 1) != 0;
+    c->print_hist = getenv("RTAMD_HIST") != nullptr;
+    c->print_sections = getenv("RTAMD_SECTION_CYCLES") != nullptr;
+    c->print_trace_lanes = getenv("RTAMD_TRACE_LANES") != nullptr;
+    rtk::Tuning& tn = c->tune;
+    auto knob = [](const char* name, int dflt, int lo, int hi) { return (int)std::min<uint32_t>((uint32_t)hi, std::max<uint32_t>((uint32_t)lo, env_u32(name, (uint32_t)dflt))); };
+    tn.oversub = knob("RTAMD_OVERSUB", tn.oversub, 1, 64);
+    tn.trace_oversub = knob("RTAMD_TRACE_OVERSUB", tn.trace_oversub, 1, 64);
+    tn.stack_lds = knob("RTAMD_STACK_LDS", tn.stack_lds, 1, 64);
+    tn.trace_min_run = 8 * knob("RTAMD_TRACE_MIN_RUN", tn.trace_min_run / 8, 1, 64);
+    tn.refill = knob("RTAMD_REFILL", tn.refill, 1, 64);
+    tn.inner_steps = knob("RTAMD_INNER_STEPS", tn.inner_steps, 1, 64);
+    tn.regen = knob("RTAMD_REGEN", tn.regen, 1, 64);
+    tn.paths_run = 24 * knob("RTAMD_PATHS_RUN", tn.paths_run / 24, 1, 64);
+    tn.settle_entry = (uint32_t)knob("RTAMD_SETTLE_ENTRY", (int)tn.settle_entry, 1, 64);
+    tn.settle_near_hits = env_u32("RTAMD_SETTLE_NEAR_HITS", tn.settle_near_hits) != 0 ? 1u : 0u;
+    tn.settled_refill = knob("RTAMD_SETTLED_REFILL", tn.settled_refill, 1, 64);
+    tn.settled_min_run = knob("RTAMD_SETTLED_MIN_RUN", tn.settled_min_run, 64, 1 << 20);
+    tn.settled_slow_min = knob("RTAMD_SETTLED_SLOW_MIN", tn.settled_slow_min, 1, 64);
+    tn.settled_fast = knob("RTAMD_SETTLED_FAST", tn.settled_fast, 0, 1);
+    tn.settled_drain = knob("RTAMD_SETTLED_DRAIN", tn.settled_drain, 1, 64);
+    tn.settled_oversub = knob("RTAMD_SETTLED_OVERSUB", tn.settled_oversub, 1, 64);
     *out = c;
     return RT_OK;
 }
@@ -479,7 +521,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->d_image_data) b.release();
     for (int s = 0; s < 2; s++)
-        for (int a = 0; a < 4; a++) c->d_state[s][a].release();
+        for (int a = 0; a < 5; a++) c->d_state[s][a].release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_rays) (void)hipHostFree(c->h_rays);
@@ -700,7 +742,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     for (auto& v : members) std::sort(v.begin(), v.end(), [&](const PrimSrc& a, const PrimSrc& b) { return id_of(a) < id_of(b); });
     // Scenes of a few dozen primitives are traced without the tree (see rtd::Scene::flat): incoherent rays take
     // different branches of even a four-node tree, which costs more lane time than testing everything in step.
-    bool flat_ok = total_prims <= env_u32("RTAMD_FLAT_MAX", 48);
+    bool flat_ok = total_prims <= c->flat_max;
     for (uint32_t g = 1; g <= ng; g++)
         if (members[g].size() > 64) flat_ok = false;
     if (nested) flat_ok = false;  // (the loop that stands in for the tree takes every instance's ray from the world ray)
@@ -713,7 +755,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         for (uint32_t g = 0; g <= ng; g++)
             if (g == 0 || c->groups[g - 1].kind != RT_GROUP_MEDIUM) fuse_boxes(c, members[g]);
 
-    const uint32_t leaf_max = std::max(1u, std::min(env_u32("RTAMD_LEAF_MAX", 1), rtd::MAX_LEAF_PRIMS));
+    const uint32_t leaf_max = std::max(1u, std::min(c->leaf_max, rtd::MAX_LEAF_PRIMS));
     std::vector<rtd::Node> nodes;
     std::vector<rtd::Prim> prims;
     std::vector<rtd::Moving> moving;
@@ -839,7 +881,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     auto ttree = std::chrono::steady_clock::now();
     rtb::Result top_r;
     std::vector<uint32_t> near0;
-    bool near0_known = false, near0_ball = false;
+    bool near0_known = false, near0_ball = false, settle_fast = false;
     uint32_t lbvh_depth = 0;
     uint64_t n_nodes_total = 0;
     int rc;
@@ -855,7 +897,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
         top_r = rtb::build(top, leaf_max, false, base, nodes, order);
         for (uint32_t oi : order) prims.push_back(make_prim(c, world[oi], moving));
         // the world primitives near the first medium (rtd::Scene::near0_n), by their place in leaf order
-        if (!flat_ok && !nested && !media_groups.empty() && env_u32("RTAMD_NEAR_LIST", 1)) {
+        if (!flat_ok && !nested && !media_groups.empty() && c->near_list) {
             const rtd::Group& M0 = dgroups[media_groups[0]];
             // a boundary that is one resting sphere: what matters is the (slightly larger) ball, not its box
             const auto& bmem = members[media_groups[0] + 1];
@@ -890,6 +932,20 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
             }
             near0_known = known;
             near0_ball = known && ball;
+            // rtd::Scene::settle_fast: nothing but resting spheres and plain colours around the settled paths
+            auto resting_sphere = [&](const PrimSrc& ps) { return ps.sphere && !(!c->sph.moving.empty() && c->sph.moving[ps.idx]); };
+            settle_fast = near0_ball && near0.size() <= 1 && media_groups.size() <= 4;
+            if (settle_fast && near0.size() == 1) {  // ... of glass
+                const PrimSrc& ps = world[order[near0[0] - base]];
+                settle_fast = resting_sphere(ps) && c->sph.mat[ps.idx] < c->mats.size() && c->mats[c->sph.mat[ps.idx]].kind == RT_MAT_DIELECTRIC;
+            }
+            for (uint32_t g : media_groups) {
+                const rt_group& G = c->groups[g];
+                const auto& mem = members[g + 1];
+                settle_fast = settle_fast && !G.has_xform && G.parent == 0 && mem.size() == 1 && resting_sphere(mem[0]) && G.mat < c->mats.size() &&
+                              c->mats[G.mat].kind == RT_MAT_ISOTROPIC && c->mats[G.mat].tex < c->texs.size() &&
+                              c->texs[c->mats[G.mat].tex].kind == RT_TEX_SOLID;
+            }
         }
         if ((rc = upload(c, c->d_prims, prims.data(), prims.size() * sizeof(rtd::Prim)))) return rc;
         if ((rc = upload(c, c->d_moving, moving.data(), moving.size() * sizeof(rtd::Moving)))) return rc;
@@ -1114,15 +1170,16 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.n_media = (uint32_t)media_groups.size();
     S.near0_n = near0_known ? (uint32_t)near0.size() : rtd::NEAR_NONE;
     S.near0_ball = near0_ball ? 1u : 0u;
+    S.settle_fast = settle_fast ? 1u : 0u;
     S.flat = flat_ok ? 1u : 0u;
     S.nested = nested ? 1u : 0u;
     S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
     c->n_perlin_tables = n_perlin;
-    S.n_perlin = env_u32("RTAMD_LDS_TABLES", 1) ? n_perlin : 0u;  // 0: noise lookups read the table from global memory
+    S.n_perlin = c->lds_tables ? n_perlin : 0u;  // 0: noise lookups read the table from global memory
     S.n_mats = (uint32_t)c->mats.size();
     S.n_texs = (uint32_t)c->texs.size();
     // small (flat) scenes: primitive, material and texture records follow the Perlin table into LDS (at most 8 KiB)
-    S.lds_scene = (flat_ok && env_u32("RTAMD_LDS_TABLES", 1) && 32ull * (n_prims_total + S.n_mats + S.n_texs) <= 8192ull) ? 1u : 0u;
+    S.lds_scene = (flat_ok && c->lds_tables && 32ull * (n_prims_total + S.n_mats + S.n_texs) <= 8192ull) ? 1u : 0u;
     S.world_first = base;
     S.world_count = (uint32_t)world.size();
 
@@ -1612,6 +1669,8 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         unsigned long long* d_stats = (unsigned long long*)c->d_rays.p;
         uint32_t* d_ovf = (uint32_t*)c->d_overflow.p;
         float4* d_rad = (float4*)c->d_radiance.p;
+        // settled paths (see k_shade / k_settled): only the uninstrumented split kernels of scenes with a near list
+        const bool settle = !fused && !c->count_visits && c->settle_ahead && rtk::scene_settles(c->scene);
         const uint64_t pix_chunk = std::min<uint64_t>(n_owned, c->capacity);
         for (uint64_t p0 = 0; p0 < n_owned; p0 += pix_chunk) {
             const uint32_t npix = (uint32_t)std::min<uint64_t>(pix_chunk, n_owned - p0);
@@ -1632,7 +1691,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                     // whole paths with regeneration: one launch, nothing queued
                     {
                         ScopedTimer tm(c, KS_PATHS);
-                        HIP_TRY(c, rtk::launch_paths(c->stream, tcfg, c->scene, rcst, batch, d_rad, d_stats, d_ovf));
+                        HIP_TRY(c, rtk::launch_paths(c->stream, c->tune, tcfg, c->scene, rcst, batch, d_rad, d_stats, d_ovf));
                     }
                     st.bounce_launches++;
                     ScopedTimer tm(c, KS_ACCUM);
@@ -1644,22 +1703,27 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 } else {
                     HIP_TRY(c, hipMemsetAsync(q.counts + 3 * rtk::NSHARD, 0, 3 * rtk::NSHARD * sizeof(uint32_t), c->stream));
                     ScopedTimer tm(c, KS_RAYGEN);
-                    HIP_TRY(c, rtk::launch_raygen(c->stream, rcst, batch, path_state(c, 0), q));
+                    HIP_TRY(c, rtk::launch_raygen(c->stream, c->tune, rcst, batch, path_state(c, 0), q));
                 }
                 for (uint32_t b = 0; b < p->max_depth; b++) {
                     const rtk::PathState in = path_state(c, b & 1), out = path_state(c, (b & 1) ^ 1);
                     if (fused || (mode == 2 && b == 0)) {
                         ScopedTimer tm(c, KS_BOUNCE);
-                        HIP_TRY(c, rtk::launch_bounce(c->stream, tcfg, c->scene, rcst, batch, in, out, q, b, bps, d_rad, d_stats, d_ovf));
+                        HIP_TRY(c, rtk::launch_bounce(c->stream, c->tune, tcfg, c->scene, rcst, batch, in, out, q, b, bps, d_rad, d_stats, d_ovf));
                     } else {
                         {
                             ScopedTimer tm(c, KS_TRACE);
-                            HIP_TRY(c, rtk::launch_trace(c->stream, tcfg, c->scene, in, q, b, bps, (float4*)c->d_hits.p, d_stats, d_ovf, c->trace_spill));
+                            HIP_TRY(c, rtk::launch_trace(c->stream, c->tune, tcfg, c->scene, in, q, b, bps, (float4*)c->d_hits.p, d_stats, d_ovf, c->trace_spill));
                         }
                         {
                             ScopedTimer tm(c, KS_SHADE);
-                            HIP_TRY(c, rtk::launch_shade(c->stream, c->scene, rcst, in, out, (const float4*)c->d_hits.p, q, b, bps, d_rad, d_stats,
-                                                         !c->count_visits && c->settle_ahead));
+                            HIP_TRY(c, rtk::launch_shade(c->stream, c->tune, c->scene, rcst, in, out, (const float4*)c->d_hits.p, q, b, bps, d_rad, d_stats,
+                                                         settle));
+                        }
+                        if (settle && b > 0) {
+                            // the paths the launch before left at the far end of `in`, each followed for as long as it stays settled
+                            ScopedTimer tm(c, KS_SETTLED);
+                            HIP_TRY(c, rtk::launch_settled(c->stream, c->tune, c->scene, rcst, in, out, q, b, d_rad, d_stats));
                         }
                     }
                     st.bounce_launches++;
@@ -1676,9 +1740,9 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                         uint32_t longest = 0;
                         uint64_t live = 0;
                         for (int k = 0; k < rtk::NSHARD; k++) {
-                            // (a shard's queue holds its settled paths at the far end; the shade kernel tiles both parts)
-                            const uint32_t both = c->h_counts[k] + (fused ? 0u : h_settled[k] + (h_settled[k] ? (uint32_t)rtk::BLOCK : 0u));
-                            longest = std::max(longest, both);
+                            // (a shard's queue holds its settled paths at the far end: k_settled takes those with a grid of its
+                            // own; each that leaves it joins the front of the next queue, so the front can grow by that many)
+                            longest = std::max(longest, c->h_counts[k] + (fused ? 0u : h_settled[k]));
                             live += c->h_counts[k] + (fused ? 0u : h_settled[k]);
                         }
                         if (c->debug_live) {  // RTAMD_DEBUG_LIVE=1: paths alive after each checked bounce (front of the queues / settled end)
@@ -1715,11 +1779,16 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (n_owned && n_samples_total) {
         st.tail_rays = c->h_rays[8];
         st.settled_rays = c->h_rays[16];
-        if (getenv("RTAMD_HIST")) { fprintf(stderr, "[rtamd] hist:"); for (int k = 17; k < 32; k++) fprintf(stderr, " %llu", c->h_rays[k]); fprintf(stderr, "\n"); }
+        if (c->print_hist) { fprintf(stderr, "[rtamd] hist:"); for (int k = 17; k < 32; k++) fprintf(stderr, " %llu", c->h_rays[k]); fprintf(stderr, "\n"); }
         st.rays = c->h_rays[0] + st.tail_rays;
         st.node_visits = c->h_rays[1];
         st.prim_tests = c->h_rays[2];
-        if (c->count_visits && getenv("RTAMD_SECTION_CYCLES")) {
+        if (c->print_sections && c->h_rays[29]) {  // builds with -DRT_SECTIONS: wave cycles per section of k_settled's loop
+            const unsigned long long* h = c->h_rays;
+            fprintf(stderr, "[rtamd] k_settled wave cycles per round: refill %.0f  other media %.0f  shade %.0f  settle test %.0f  (rounds %llu, rays %llu)\n",
+                    h[24] / (double)h[29], h[25] / (double)h[29], h[26] / (double)h[29], h[27] / (double)h[29], h[29], h[16]);
+        }
+        if (c->count_visits && c->print_sections) {
             // instrumented fused kernel: wave cycles per section, summed over waves (words 3..6), wave tiles (7)
             const unsigned long long* h = c->h_rays;
             double tot = (double)(h[3] + h[4] + h[5] + h[6]);
@@ -1727,7 +1796,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
                 fprintf(stderr, "[rtamd] wave cycles per tile: fetch/raygen %.0f  trace %.0f  shade %.0f  compact %.0f  (tiles %llu)\n",
                         h[3] / (double)h[7], h[4] / (double)h[7], h[5] / (double)h[7], h[6] / (double)h[7], h[7]);
         }
-        if (c->count_visits && getenv("RTAMD_TRACE_LANES") && c->h_rays[12]) {
+        if (c->count_visits && c->print_trace_lanes && c->h_rays[12]) {
             // instrumented persistent trace kernel: how full its waves were
             const unsigned long long* h = c->h_rays;
             fprintf(stderr,
@@ -1739,14 +1808,16 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         if (c->h_counts[rtk::NSHARD]) return fail(c, RT_ERR_UNSUPPORTED, "traversal stack overflow");
     }
     if (c->profile) {
-        double ms[KS_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+        double ms[KS_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (auto& u : c->ev_used) {
             float t = 0;
             if (hipEventElapsedTime(&t, c->ev_pool[u.second.first], c->ev_pool[u.second.second]) == hipSuccess) ms[u.first] += t;
+            if (c->debug_live) fprintf(stderr, "[rtamd] launch slot %d: %.3f ms\n", u.first, t);  // (1 trace, 2 shade, 4 bounce, 7 settled)
             if (u.first == KS_TRACE) st.trace_launches++;
             if (u.first == KS_SHADE) st.shade_launches++;
             if (u.first == KS_BOUNCE) st.bounce_kernel_launches++;
             if (u.first == KS_PATHS) st.paths_launches++;
+            if (u.first == KS_SETTLED) st.settled_launches++;
         }
         st.raygen_ms = ms[KS_RAYGEN];
         st.trace_ms = ms[KS_TRACE];
@@ -1755,6 +1826,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
         st.bounce_ms = ms[KS_BOUNCE];
         st.tail_ms = ms[KS_TAIL];
         st.paths_ms = ms[KS_PATHS];
+        st.settled_ms = ms[KS_SETTLED];
     }
     st.render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = st;

@@ -153,13 +153,14 @@ DEV void stream_key(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t& k0
     k1 = mix32(k0 ^ mix32(sample + 0x68E31DA4U));
 }
 // f64 uniform of medium `m` at bounce `b`: rand gen_range(0.0..1.0) from a (hi,lo) word pair
-DEV double medium_xi(uint32_t k0, uint32_t k1, uint32_t bounce, uint32_t medium) {
-    uint32_t salt = mix32(medium + 0x3C6EF372U);
+DEV uint32_t medium_salt(uint32_t medium) { return mix32(medium + 0x3C6EF372U); }
+DEV double medium_xi_salted(uint32_t k0, uint32_t k1, uint32_t bounce, uint32_t salt) {
     uint32_t hi = mix32((k0 + 0x80000000U + 2u * bounce) ^ k1 ^ salt);
     uint32_t lo = mix32((k0 + 0x80000001U + 2u * bounce) ^ k1 ^ salt);
     unsigned long long u = ((unsigned long long)hi << 32) | lo;
     return __longlong_as_double((long long)((u >> 12) | 0x3FF0000000000000ULL)) - 1.0;
 }
+DEV double medium_xi(uint32_t k0, uint32_t k1, uint32_t bounce, uint32_t medium) { return medium_xi_salted(k0, k1, bounce, medium_salt(medium)); }
 DEV f3 rand_range3(Rng& r, float lo, float hi) {
     float x = r.range(lo, hi), y = r.range(lo, hi), z = r.range(lo, hi);
     return {x, y, z};
@@ -219,6 +220,32 @@ DEV void quotient_pair(float n0, float n1, float d, float& t0, float& t1) {
     }
 }
 DEV void plane_pair(float k0, float k1, float o, float d, float& t0, float& t1) { quotient_pair(k0 - o, k1 - o, d, t0, t1); }
+// Sphere::intersect up to the root that is taken (shapes.rs:117-139): the near root if it lies in [tmin, tmax], else the far one.
+DEV bool sphere_candidate(f3 c, float r, f3 o, f3 d, float a, float tmin, float tmax, float& t) {
+    f3 oc = o - c;
+    float half_b = dot3(oc, d);
+    float cc = dot3(oc, oc) - r * r;
+    float disc = half_b * half_b - a * cc;
+    if (disc < 0.0f) return false;
+    float sq = __builtin_sqrtf(disc);
+    t = (-half_b - sq) / a;
+    if (t < tmin || t > tmax) {
+        t = (-half_b + sq) / a;
+        if (t < tmin || t > tmax) return false;
+    }
+    return true;
+}
+// Both roots of a sphere without any range (what the boundary queries of a medium pick from): false when the line misses.
+DEV bool sphere_roots(f3 c, float r, f3 o, f3 d, float a, float& c0, float& c1) {
+    f3 oc = o - c;
+    float half_b = dot3(oc, d);
+    float cc = dot3(oc, oc) - r * r;
+    float disc = half_b * half_b - a * cc;
+    if (disc < 0.0f) return false;
+    float sq = __builtin_sqrtf(disc);
+    quotient_pair(-half_b - sq, -half_b + sq, a, c0, c1);
+    return true;
+}
 // One rect side inside Scene::intersect over the box's sides (scene.rs:27-41): accepted when t lies in
 // [tmin, closest] and the in-plane point inside the bounds, all inclusive; a later side with the same t wins.
 DEV void box_side(float t, float p0, float p1, float min0, float min1, float max0, float max1, float tmin, uint32_t s, float& closest,
@@ -245,18 +272,7 @@ DEV bool prim_candidate(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float 
     if (kind <= PK_MOVING_SPHERE) {  // shapes.rs:117-139, 195-217
         f3 c{A.x, A.y, A.z};
         if (kind == PK_MOVING_SPHERE) c = moving_center(S, c, __float_as_uint(B.w), time);
-        float r = A.w;
-        f3 oc = o - c;
-        float half_b = dot3(oc, d);
-        float cc = dot3(oc, oc) - r * r;
-        float disc = half_b * half_b - a * cc;
-        if (disc < 0.0f) return false;
-        float sq = __builtin_sqrtf(disc);
-        t = (-half_b - sq) / a;
-        if (t < tmin || t > tmax) {
-            t = (-half_b + sq) / a;
-            if (t < tmin || t > tmax) return false;
-        }
+        if (!sphere_candidate(c, A.w, o, d, a, tmin, tmax, t)) return false;
     } else if (BOXES && kind == PK_BOX) {  // Box2::intersect = Scene::intersect over the six sides (shapes.rs:474-477)
         const f3 lo{A.x, A.y, A.z}, hi{A.w, B.x, B.w};
         float tz0, tz1, ty0, ty1, tx0, tx1;
@@ -336,15 +352,7 @@ DEV uint32_t prim_roots(const Scene& S, uint32_t pi, f3 o, f3 d, float a, float 
     if (kind <= PK_MOVING_SPHERE) {  // shapes.rs:117-139, 195-217
         f3 c{A.x, A.y, A.z};
         if (kind == PK_MOVING_SPHERE) c = moving_center(S, c, __float_as_uint(B.w), time);
-        float r = A.w;
-        f3 oc = o - c;
-        float half_b = dot3(oc, d);
-        float cc = dot3(oc, oc) - r * r;
-        float disc = half_b * half_b - a * cc;
-        if (disc < 0.0f) return 0u;
-        float sq = __builtin_sqrtf(disc);
-        quotient_pair(-half_b - sq, -half_b + sq, a, c0, c1);
-        return 3u;
+        return sphere_roots(c, A.w, o, d, a, c0, c1) ? 3u : 0u;
     }
     int ax = kind == PK_RECT_XY ? 2 : (kind == PK_RECT_XZ ? 1 : 0);  // shapes.rs:279-292, 343-356, 407-420
     int a0 = ax == 0 ? 1 : 0;
@@ -399,6 +407,20 @@ DEV bool boundary_pair(const Scene& S, uint32_t first, uint32_t cnt, f3 o, f3 d,
 
 DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tmin, float tbest, float& tn);
 DEV f3 fast_rcp3(f3 d);
+// The free flight of ConstantMedium::intersect (shapes.rs:666-689) once the boundary is crossed at r1 and r2: the
+// distances are clamped to [tmin, closest hit so far], the flight length is -1/density * ln(xi) in f64 with xi the
+// medium's draw, and a flight that ends inside gives the hit at t.  len: the ray's length |d| (the reference divides by it twice).
+DEV bool medium_flight(float r1, float r2, float tmin, float best_t, double len, double neg_inv_density, double xi, float& t) {
+    if (r1 < tmin) r1 = tmin;
+    if (r2 > best_t) r2 = best_t;
+    if (r1 >= r2) return false;
+    if (r1 < 0.0f) r1 = 0.0f;
+    double inside = (double)(r2 - r1) / len;
+    double hit_distance = neg_inv_density * log(xi);
+    if (hit_distance > inside) return false;
+    t = r1 + (float)(hit_distance / len);
+    return true;
+}
 // ConstantMedium::intersect (shapes.rs:648-701).  wo/wd: the world ray.  A medium that reports a hit
 // replaces the closest hit so far unchecked, as Scene::intersect does (scene.rs:33-37): its final_t may
 // lie beyond best.t because shapes.rs:676-683 divides by the ray length twice.
@@ -440,16 +462,10 @@ DEV void test_medium(const Scene& S, uint32_t g, f3 wo, f3 wd, float time, float
         if (!list_closest(S, first, n, o, d, a, time, -INF_F, INF_F, r1)) return;
         if (!list_closest(S, first, n, o, d, a, time, r1 + 0.0001f, INF_F, r2)) return;
     }
-    if (r1 < tmin) r1 = tmin;
-    if (r2 > best.t) r2 = best.t;
-    if (r1 >= r2) return;
-    if (r1 < 0.0f) r1 = 0.0f;
-    double len = (double)(G.has_xform ? len3(wd) : __builtin_sqrtf(a));  // (without a boundary transform a is |wd|^2 already)
-    double inside = (double)(r2 - r1) / len;
-    double xi = medium_xi(k0, k1, bounce, G.order);
-    double hit_distance = G.neg_inv_density * log(xi);
-    if (hit_distance > inside) return;
-    best.t = r1 + (float)(hit_distance / len);
+    const double len = (double)(G.has_xform ? len3(wd) : __builtin_sqrtf(a));  // (without a boundary transform a is |wd|^2 already)
+    float t;
+    if (!medium_flight(r1, r2, tmin, best.t, len, G.neg_inv_density, medium_xi(k0, k1, bounce, G.order), t)) return;
+    best.t = t;
     best.prim = HIT_MEDIUM_BIT | g;
     best.grp = -1;
     best.key = MEDIUM_KEY_BASE + G.order;

@@ -150,6 +150,9 @@ struct Scene {
     // the boundary is transformed, the world's tree was built on the device, more than 32 such primitives).
     uint32_t near0_n;
     uint32_t near0_ball;  // != 0: that boundary is one resting sphere, and the list was made for the ball 1.001 times its radius
+    // != 0 (needs near0_ball): every medium (at most 4) is one resting sphere in world space with a plain-colour phase
+    // material, and the near list holds at most one primitive, a resting sphere: k_settled may take its specialised step
+    uint32_t settle_fast;
 };
 constexpr uint32_t NEAR_NONE = 0xFFFFFFFFu;
 

@@ -21,8 +21,11 @@ constexpr int MAX_BLOCKS_PER_SHARD = 512;  // upper bound of any grid; launches 
 struct PathState {
     float4* o_time;    // origin.xyz, time
     float4* d_slot;    // direction.xyz, bits(slot)
-    float4* thr_meta;  // throughput.xyz, distance at which the first medium takes the ray if that is settled already (else 0)
+    float4* thr_meta;  // throughput.xyz, bits(bounce number of the ray this entry describes)
     uint2* key;        // RNG stream key (k0, k1)
+    // Entries at the far end of a shard only (paths whose next hit is settled, see k_shade): > 0 the distance at which the
+    // first medium takes the ray, < 0 minus the distance at which it meets the one primitive near that medium.
+    float* settled;
 };
 
 // counts: 6 x NSHARD words.  Bounce b reads counts[b % 3], appends to counts[(b + 1) % 3] and clears
@@ -58,6 +61,27 @@ struct Batch {
     uint32_t q_log2;
 };
 
+// Launch-shape knobs.  A context reads them from the environment ONCE, when it is created (rt_ctx_create), and hands them
+// to every launcher; nothing on a launch path reads the environment.
+struct Tuning {
+    int oversub = 16;        // RTAMD_OVERSUB: grid of the per-bounce kernels, in rounds of resident blocks
+    int trace_oversub = 2;   // RTAMD_TRACE_OVERSUB: the same for the persistent trace kernel
+    int stack_lds = 8;       // RTAMD_STACK_LDS: traversal-stack entries k_trace keeps in LDS per lane (deeper ones spill)
+    int trace_min_run = 128; // RTAMD_TRACE_MIN_RUN (x8): fewest rays a wave of k_trace is given to refill from
+    int refill = 24;         // RTAMD_REFILL: idle lanes at which a wave of k_trace fetches new rays
+    int inner_steps = 4;     // RTAMD_INNER_STEPS: inner nodes per round of k_trace before the leaf step
+    int regen = 8;           // RTAMD_REGEN: idle lanes at which a wave of k_paths starts new camera rays
+    int paths_run = 1536;    // RTAMD_PATHS_RUN (x24): path slots per wave of k_paths
+    uint32_t settle_entry = 8;      // RTAMD_SETTLE_ENTRY: lanes of a wave that must qualify for its paths to be settled ahead
+    uint32_t settle_near_hits = 1;  // RTAMD_SETTLE_NEAR_HITS: hits on the one primitive near a ball-shaped medium are settled too
+    int settled_refill = 16;        // RTAMD_SETTLED_REFILL: idle lanes at which a wave of k_settled takes new paths
+    int settled_min_run = 128;      // RTAMD_SETTLED_MIN_RUN: fewest paths a wave of k_settled is given
+    int settled_drain = 24;         // RTAMD_SETTLED_DRAIN: a wave of k_settled whose run is used up hands its paths on once fewer are left
+    int settled_slow_min = 4;       // RTAMD_SETTLED_SLOW_MIN: lanes of a wave of k_settled that must wait for the general step before it runs
+    int settled_fast = 1;           // RTAMD_SETTLED_FAST=0: never the step specialised for sphere-shaped media (Scene::settle_fast)
+    int settled_oversub = 1;        // RTAMD_SETTLED_OVERSUB: grid of k_settled, in rounds of resident blocks
+};
+
 struct TraceCfg {
     int stack_entries;  // per-lane traversal stack in LDS (Scene::stack_cap)
     bool has_groups;    // scene holds instances / media
@@ -67,23 +91,29 @@ struct TraceCfg {
 
 // stats: 64-bit words: [0] += rays traced by the per-bounce kernels; with count_visits also [1] += inner nodes
 // fetched, [2] += primitive records tested ([3..7]: section cycles of the instrumented fused kernel);
-// [8] += rays traced by the tail kernel; [16] += rays k_shade took from the settled end of the queues (also in [0]).
+// [8] += rays traced by the tail kernel; [16] += rays k_settled followed without the tree walk (also in [0]).
 
 // ---- split pipeline: raygen, then per bounce trace + shade --------------------------------------------
-hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q);
+hipError_t launch_raygen(hipStream_t s, const Tuning& tn, const RenderConst& rc, const Batch& batch, PathState out, Queues q);
 // Global memory behind the LDS part of k_trace's traversal stacks; grown by launch_trace as needed, owned by the caller.
 struct SpillArea {
     void* p = nullptr;
     size_t bytes = 0;
 };
-hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, PathState in, Queues q,
+hipError_t launch_trace(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, const rtd::Scene& scene, PathState in, Queues q,
                         uint32_t bounce, uint32_t blocks_per_shard, float4* hits, unsigned long long* stats,
                         uint32_t* overflow_flag, SpillArea& spill);
-hipError_t launch_shade(hipStream_t s, const rtd::Scene& scene, const RenderConst& rc, PathState in, PathState out,
+hipError_t launch_shade(hipStream_t s, const Tuning& tn, const rtd::Scene& scene, const RenderConst& rc, PathState in, PathState out,
                         const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
                         unsigned long long* stats, bool may_settle);
+// true when launch_shade(..., may_settle = true) queues settled paths for this scene, i.e. launch_settled has to follow
+bool scene_settles(const rtd::Scene& scene);
+// The paths launch `bounce - 1` of k_shade queued at the far end of `in`: each is followed in registers, bounce after
+// bounce, for as long as its next hit can be settled without the tree; a path that leaves is appended to the front of `out`.
+hipError_t launch_settled(hipStream_t s, const Tuning& tn, const rtd::Scene& scene, const RenderConst& rc, PathState in, PathState out,
+                          Queues q, uint32_t bounce, float4* radiance, unsigned long long* stats);
 // ---- fused pipeline: one kernel per bounce (bounce 0 generates its camera rays itself) ---------------------
-hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc,
+hipError_t launch_bounce(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc,
                          const Batch& batch, PathState in, PathState out, Queues q, uint32_t bounce,
                          uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
                          uint32_t* overflow_flag);
@@ -92,7 +122,7 @@ hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& s
                          Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance, unsigned long long* stats,
                          uint32_t* overflow_flag);
 // ---- whole paths with regeneration (flat scenes): one launch per batch, no queues --------------------------------
-hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc, const Batch& batch,
+hipError_t launch_paths(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, const rtd::Scene& scene, const RenderConst& rc, const Batch& batch,
                         float4* radiance, unsigned long long* stats, uint32_t* overflow_flag);
 
 hipError_t launch_accumulate(hipStream_t s, const float4* radiance, const Batch& batch, uint32_t width, float* accum_rgb);

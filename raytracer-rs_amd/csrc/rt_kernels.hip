@@ -36,8 +36,11 @@ namespace {
 struct PathRegs {
     f3 o, d, T;
     float time;
-    uint32_t k0, k1, slot;  // every path of one launch is at the same bounce, so the bounce is not stored
-    // != 0: the hit of this ray, found out by the k_shade that made the ray ("settled ahead", see there): > 0 the distance at
+    uint32_t k0, k1, slot;
+    // Bounce number of the ray (o, d): how many scatterings lie behind it.  In most launches every path is at the launch's
+    // own bounce; paths that k_settled has followed in registers are ahead of it, so the number travels with the path.
+    uint32_t bounce = 0u;
+    // != 0: the hit of this ray, found out by the kernel that made the ray ("settled ahead", see k_shade): > 0 the distance at
     // which the first medium takes it, < 0 minus the distance at which it meets the one primitive near that medium.  Such
     // a path waits at the far end of its queue, where the trace kernel does not look.
     float settled = 0.0f;
@@ -96,6 +99,7 @@ DEV void camera_path(const rtk::RenderConst& rc, const rtk::Batch& b, uint32_t s
     p.k0 = rng.k0;
     p.k1 = rng.k1;
     p.slot = slot;
+    p.bounce = 0u;
 }
 
 DEV void load_path(const rtk::PathState& st, uint32_t idx, PathRegs& p) {
@@ -108,17 +112,18 @@ DEV void load_path(const rtk::PathState& st, uint32_t idx, PathRegs& p) {
     p.T = {tm.x, tm.y, tm.z};
     p.k0 = key.x;
     p.k1 = key.y;
-    p.settled = tm.w;
+    p.bounce = __float_as_uint(tm.w);
+    p.settled = 0.0f;
 }
 DEV void store_path(const rtk::PathState& st, uint32_t idx, const PathRegs& p) {
     st.o_time[idx] = make_float4(p.o.x, p.o.y, p.o.z, p.time);
     st.d_slot[idx] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(p.slot));
-    st.thr_meta[idx] = make_float4(p.T.x, p.T.y, p.T.z, p.settled);
+    st.thr_meta[idx] = make_float4(p.T.x, p.T.y, p.T.z, __uint_as_float(p.bounce));
     st.key[idx] = make_uint2(p.k0, p.k1);
 }
 
 // One step of ray_color (main.rs:44-63) after the hit is known.  Returns true when the path goes on (p is
-// then the scattered ray with the updated throughput); otherwise its radiance has been written.
+// then the scattered ray of bounce + 1 with the updated throughput); otherwise its radiance has been written.
 // Radiance of a path that has ended.  Adding a zero (of either sign) to a pixel's sum changes nothing, so zeros are
 // not written when the buffer starts out cleared.
 DEV void end_path(const rtk::RenderConst& rc, float4* __restrict__ radiance, uint32_t slot, f3 L) {
@@ -159,6 +164,7 @@ DEV bool shade_path(const Scene& S, const LdsTables& tabs, const rtk::RenderCons
         p.T = p.T * att;
         p.o = rec.point;
         p.d = dir;
+        p.bounce = bounce + 1u;
         return true;
     }
     f3 E{0.0f, 0.0f, 0.0f};  // main.rs:57-59
@@ -224,6 +230,7 @@ DEV void compact_store2(CompactLds& lds, uint32_t parity, bool a, bool b, const 
         uint32_t off = lds.block_base_b[parity] + lane_prefix(mask_b);
         for (uint32_t w = 0; w < wave; w++) off += lds.wave_tot_b[parity][w];
         store_path(out, shard_base + cap_shard - 1u - off, p);
+        out.settled[shard_base + cap_shard - 1u - off] = p.settled;
     }
 }
 
@@ -491,15 +498,50 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
 // final_scene's blue sphere (main.rs:281-284: mean free path 5 in a radius of 70, nothing absorbed) holds 5 % of the paths
 // for all 50 bounces, a third of the frame's rays.  While such a ray starts inside the boundary, the only surfaces it can
 // meet before it leaves are the few whose box meets the boundary (Scene::near0_n, found at commit), and the medium sees
-// surfaces only through min(r2, t) with r2 on the boundary.  So k_shade tests the ray it has just made against those
+// surfaces only through min(r2, t) with r2 on the boundary.  So the kernel that has just made the ray tests it against those
 // primitives and then lets the first medium decide, exactly as the next bounce would after the tree walk: if the medium
-// takes the ray, that IS the next bounce's answer for this medium; the distance travels with the path, and the path
-// is queued at the far end of its shard (a second count per shard, rtk::Queues), where the trace kernel does not look.
-// The next k_shade takes those paths as tiles of their own, with the hit made from the stored distance and the media
-// starting at the second one.  If the medium does not take the ray (it leaves, or meets a surface), nothing is settled
-// and the ray goes through the tree as usual.  Paths join when at least `entry_lanes` lanes of their wave qualify (the
-// test costs the wave the same for one lane as for 64); a tile of settled paths tests all of its own.
-// SETTLE: compiled with that (launched for scenes whose first medium has a known near list); without it the plain loop.
+// takes the ray, that IS the next bounce's answer for this medium, and the tree is never walked for it.
+//
+// settle_next: the test itself, for the ray p now holds (bounce p.bounce).  Returns 0 when nothing is settled (the origin is
+// outside the boundary, or the ray leaves or meets another surface: it then goes through the tree as usual), > 0 the distance
+// at which the first medium takes it, < 0 minus the distance at which it meets the one primitive near a ball-shaped boundary
+// (near_prim; the glass around final_scene's medium, from inside) with the hit point still in the ball: no other primitive
+// reaches in there, so that hit is the tree's answer too.
+template <bool NESTED>
+DEV float settle_next(const Scene& S, const PathRegs& p, uint32_t medium0, uint32_t near_prim) {
+    const Group& G = S.groups[S.media[0]];
+    bool inside = p.o.x >= G.blo[0] && p.o.x <= G.bhi[0] && p.o.y >= G.blo[1] && p.o.y <= G.bhi[1] && p.o.z >= G.blo[2] &&
+                  p.o.z <= G.bhi[2];
+    float4 sph = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (S.near0_ball) {  // (the list holds what meets the ball of 1.001 radii: the origin within 1.0005 of them)
+        sph = *reinterpret_cast<const float4*>(S.prims + (G.root_ref & 0x03FFFFFFu));
+        const f3 oc = p.o - mk3(sph.x, sph.y, sph.z);
+        const float rr = sph.w * 1.0005f;
+        inside = inside && dot3(oc, oc) <= rr * rr;
+    }
+    if (!inside) return 0.0f;
+    Hit nh;
+    nh.t = INF_F;
+    nh.prim = HIT_NONE;
+    nh.grp = -1;
+    nh.key = 0;
+    const float a = dot3(p.d, p.d);
+    for (uint32_t k = 0; k < S.near0_n; k++) test_prim<false>(S, S.media[S.n_media + k], p.o, p.d, a, p.time, 0.005f, -1, nh);
+    test_medium<NESTED>(S, S.media[0], p.o, p.d, p.time, 0.005f, p.k0, p.k1, p.bounce, nh);
+    if (nh.prim == medium0 && nh.t > 0.0f) return nh.t;
+    if (nh.prim == near_prim && nh.t > 0.0f) {
+        const f3 pc = (p.o + nh.t * p.d) - mk3(sph.x, sph.y, sph.z);
+        const float rr = sph.w * 1.0005f;
+        if (dot3(pc, pc) <= rr * rr) return -nh.t;
+    }
+    return 0.0f;
+}
+
+// k_shade.  SETTLE: compiled with the test above (launched for scenes whose first medium has a known near list): a path
+// that has just scattered in the first medium (or off the one primitive near it) and whose next hit is settled is queued
+// at the far end of its shard with that distance (a second count per shard, rtk::Queues), where the trace kernel does not
+// look; k_settled takes it from there.  Paths are tested when at least `entry_lanes` lanes of their wave qualify (the test
+// costs the wave the same for one lane as for 64).  Every path carries its own bounce number (see PathRegs).
 template <bool NESTED, bool SETTLE>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
                                                        const float4* __restrict__ hits, rtk::Queues q, uint32_t bounce,
@@ -511,11 +553,11 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
     St.stack_cap = 0;
     const LdsTables L = stage_tables(St, stack);
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
+    const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
+    uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
+    const uint32_t shard_base = shard * q.cap_shard;
+    uint32_t parity = 0;
     if (!SETTLE) {
-        const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
-        uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
-        const uint32_t shard_base = shard * q.cap_shard;
-        uint32_t parity = 0;
         for (uint32_t base = j0 * rtk::BLOCK; base < n; base += stride * rtk::BLOCK, parity ^= 1u) {
             const uint32_t i = base + threadIdx.x;
             bool alive = false;
@@ -535,50 +577,27 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
         }
         return;
     }
-    const bool settle = true;
-    const uint32_t medium0 = settle ? (HIT_MEDIUM_BIT | S.media[0]) : 0u;
+    const uint32_t medium0 = HIT_MEDIUM_BIT | S.media[0];
     // the single primitive near a ball-shaped boundary, whose hits from inside can be settled as well (else: no such index)
-    const uint32_t near_prim = (settle && S.near0_ball && S.near0_n == 1u && near_hits) ? S.media[S.n_media] : 0x7FFFFFFFu;
-    const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
-    const uint32_t n_settled = q.counts[(3u + bounce % 3u) * rtk::NSHARD + shard];
-    uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
+    const uint32_t near_prim = (S.near0_ball && S.near0_n == 1u && near_hits) ? S.media[S.n_media] : 0x7FFFFFFFu;
     uint32_t* out_settled = q.counts + (3u + (bounce + 1u) % 3u) * rtk::NSHARD + shard;
-    const uint32_t shard_base = shard * q.cap_shard;
-    if (j0 == 0 && threadIdx.x == 0) {
-        q.counts[(3u + (bounce + 2u) % 3u) * rtk::NSHARD + shard] = 0;  // the next bounce appends there
-        if (n_settled) {  // rays that never saw the trace kernel
-            atomicAdd(stats, (unsigned long long)n_settled);
-            atomicAdd(stats + 16, (unsigned long long)n_settled);
-        }
-    }
-    const uint32_t tiles = (n + rtk::BLOCK - 1u) / rtk::BLOCK, tiles_settled = (n_settled + rtk::BLOCK - 1u) / rtk::BLOCK;
-    uint32_t parity = 0;
-    for (uint32_t tile = j0; tile < tiles + tiles_settled; tile += stride, parity ^= 1u) {
-        const bool settled_tile = tile >= tiles;  // (the same for the whole block)
-        const uint32_t i = (settled_tile ? tile - tiles : tile) * rtk::BLOCK + threadIdx.x;
-        const uint32_t at = shard_base + (settled_tile ? q.cap_shard - 1u - i : i);
+    if (j0 == 0 && threadIdx.x == 0) q.counts[(3u + (bounce + 2u) % 3u) * rtk::NSHARD + shard] = 0;  // the next bounce appends there
+    for (uint32_t base = j0 * rtk::BLOCK; base < n; base += stride * rtk::BLOCK, parity ^= 1u) {
+        const uint32_t i = base + threadIdx.x;
         bool alive = false, candidate = false;
         PathRegs p;
-        if (i < (settled_tile ? n_settled : n)) {
-            load_path(in, at, p);
+        if (i < n) {
+            load_path(in, shard_base + i, p);
+            float4 hv = hits[shard_base + i];
             Hit h;
-            if (settled_tile) {  // (> 0: the first medium at that distance; < 0: the one primitive near it)
-                h.t = __builtin_fabsf(p.settled);
-                h.prim = p.settled > 0.0f ? medium0 : near_prim;
-                h.grp = -1;
-                h.key = 0;
-            } else {
-                float4 hv = hits[at];
-                h.t = hv.x;
-                h.prim = __float_as_uint(hv.y);
-                h.grp = __float_as_int(hv.z);
-                h.key = __float_as_uint(hv.w);
-            }
-            p.settled = 0.0f;
-            for (uint32_t m = settled_tile ? 1u : 0u; m < S.n_media; m++)
-                test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce, h);
+            h.t = hv.x;
+            h.prim = __float_as_uint(hv.y);
+            h.grp = __float_as_int(hv.z);
+            h.key = __float_as_uint(hv.w);
+            for (uint32_t m = 0; m < S.n_media; m++)
+                test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, p.bounce, h);
 #ifdef RT_HIST
-            if (!settled_tile && bounce >= 16u) {
+            if (p.bounce >= 16u) {
                 uint32_t cls = 4u;
                 if (h.prim == HIT_NONE) cls = 0u;
                 else if (h.prim == medium0) cls = 1u;
@@ -588,43 +607,337 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
                 atomicAdd(stats + 17 + cls, 1ull);
             }
 #endif
-            alive = shade_path<NESTED>(S, L, rc, p, h, bounce, radiance);
-            candidate = alive && settle && (h.prim == medium0 || h.prim == near_prim);
+            alive = shade_path<NESTED>(S, L, rc, p, h, p.bounce, radiance);
+            candidate = alive && (h.prim == medium0 || h.prim == near_prim);
         }
-        if (settle && (uint32_t)__popcll(__ballot(candidate)) >= (settled_tile ? 1u : entry_lanes) && candidate) {
-            const Group& G = S.groups[S.media[0]];
-            bool inside = p.o.x >= G.blo[0] && p.o.x <= G.bhi[0] && p.o.y >= G.blo[1] && p.o.y <= G.bhi[1] && p.o.z >= G.blo[2] &&
-                          p.o.z <= G.bhi[2];
-            if (S.near0_ball) {  // (the list holds what meets the ball of 1.001 radii: the origin within 1.0005 of them)
-                const float4 sph = *reinterpret_cast<const float4*>(S.prims + (G.root_ref & 0x03FFFFFFu));
-                const f3 oc = p.o - mk3(sph.x, sph.y, sph.z);
-                const float rr = sph.w * 1.0005f;
-                inside = inside && dot3(oc, oc) <= rr * rr;
-            }
-            if (inside) {
-                Hit nh;
-                nh.t = INF_F;
-                nh.prim = HIT_NONE;
-                nh.grp = -1;
-                nh.key = 0;
-                const float a = dot3(p.d, p.d);
-                for (uint32_t k = 0; k < S.near0_n; k++) test_prim<false>(S, S.media[S.n_media + k], p.o, p.d, a, p.time, 0.005f, -1, nh);
-                test_medium<NESTED>(S, S.media[0], p.o, p.d, p.time, 0.005f, p.k0, p.k1, bounce + 1u, nh);
-                if (nh.prim == medium0 && nh.t > 0.0f) {
-                    p.settled = nh.t;
-                } else if (nh.prim == near_prim && nh.t > 0.0f) {
-                    // The medium lets the ray pass and it meets the one primitive near the boundary (the glass around the
-                    // medium, from inside).  That is the tree's answer as well if the hit point still lies in the ball: no
-                    // other primitive reaches in there.
-                    const float4 sph = *reinterpret_cast<const float4*>(S.prims + (G.root_ref & 0x03FFFFFFu));
-                    const f3 pc = (p.o + nh.t * p.d) - mk3(sph.x, sph.y, sph.z);
-                    const float rr = sph.w * 1.0005f;
-                    if (dot3(pc, pc) <= rr * rr) p.settled = -nh.t;
-                }
-            }
-        }
+        if ((uint32_t)__popcll(__ballot(candidate)) >= entry_lanes && candidate) p.settled = settle_next<NESTED>(S, p, medium0, near_prim);
         compact_store2(clds, parity, alive && p.settled == 0.0f, alive && p.settled != 0.0f, p, out, out_count, out_settled, shard_base,
                        q.cap_shard);
+    }
+}
+
+// The settled paths, followed in registers.  Launch `bounce` takes the paths that launch `bounce - 1` of k_shade (or of this
+// kernel's predecessor) left at the far end of `in`.  Each wave owns a run of them and keeps its lanes busy across paths, as
+// k_trace does: a lane makes the hit from the stored distance, lets the other media have their say, shades (one step of
+// ray_color, main.rs:44-63), and tests the ray it has just made with settle_next; while that settles the next hit too
+// (about nineteen times in twenty inside final_scene's blue sphere) the path stays in its lane and its state never touches
+// memory.  A path that leaves (its ray goes out of the boundary or meets another surface) waits in its lane until the wave
+// next refills, when all such paths of the wave are appended to the FRONT of `out` with one atomic: the next launch of
+// k_trace walks the tree for them, at whatever bounce each has reached.  Draws are keyed by (stream, bounce), so the image
+// is the one the bounce-per-launch kernels give, bit for bit.  Counted in stats[0] and stats[16]: one ray per step.
+//
+// FAST (Scene::settle_fast, decided at commit): every medium of the scene is a resting sphere in world space filled with a
+// plain colour, and at most one primitive, a resting sphere too, lies near the first medium (final_scene: the blue ball
+// inside its glass shell and the fog around everything, main.rs:279-284).  Then a step in the first medium needs no record
+// from memory at all: the few numbers that describe the media sit in LDS (FastLds, filled once per block), the arithmetic
+// is the same device functions in the same order as the general code (sphere_roots / pick_root / medium_flight for a
+// medium, sphere_candidate for the primitive, the isotropic scatter of shade_path), so the bits are the same.  What such
+// a step cannot do -- shade a hit on the primitive near the medium (glass: the whole material code) -- is left to the general
+// step, and lanes that need that one WAIT until `slow_min` of their wave do (or nothing else is left to do): run for two or
+// three lanes in every round it would cost each round more than the fast step itself.
+struct FastMedium {
+    float cx, cy, cz, r;
+    double neg_inv_density;
+    uint32_t salt, hit, key, pad;
+    float col[3];
+    float inv_density_lo;  // a float just below 1 / density (fast_medium_misses)
+};
+struct FastLds {
+    FastMedium m[4];
+    float blo[3], bhi[3];        // widened box of the first medium's boundary (Group::blo / bhi)
+    float ncx, ncy, ncz, nr;     // the one primitive near the first medium (a resting sphere of glass), if the scene has one
+    float near_ior;
+    uint32_t same_sphere;        // that sphere equals the first medium's boundary bit for bit (final_scene: main.rs:279-282)
+};
+// The free flight of such a medium once the roots of its sphere are known (test_medium's single-sphere case).
+DEV bool fast_medium_flight(const FastMedium& M, bool line_hits, float c0, float c1, float a, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce,
+                            float best_t, float& t) {
+    float r1, r2;
+    const uint32_t have = line_hits ? 3u : 0u;
+    if (!pick_root(have, c0, c1, -INF_F, INF_F, r1)) return false;
+    if (!pick_root(have, c0, c1, r1 + 0.0001f, INF_F, r2)) return false;
+    return medium_flight(r1, r2, tmin, best_t, (double)__builtin_sqrtf(a), M.neg_inv_density, medium_xi_salted(k0, k1, bounce, M.salt), t);
+}
+// ConstantMedium::intersect for such a medium: test_medium's single-sphere case with the record in LDS.
+DEV bool fast_medium(const FastMedium& M, f3 o, f3 d, float a, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce, float best_t, float& t) {
+    float c0, c1;
+    const bool line_hits = sphere_roots(mk3(M.cx, M.cy, M.cz), M.r, o, d, a, c0, c1);
+    return fast_medium_flight(M, line_hits, c0, c1, a, tmin, k0, k1, bounce, best_t, t);
+}
+// true: fast_medium certainly returns false for a closest hit at best_t (> 0), whatever the sphere -- decided from the
+// medium's draw alone, in f32.  The medium takes a ray only if its flight -ln(xi) / density ends within the part of the ray
+// inside it, which is shorter than best_t / |d| (medium_flight: r1 >= tmin > 0, r2 <= best_t).  The hardware log2 of the
+// rounded draw is within 2e-7 relative and 6e-8 absolute of ln(xi) / ln 2; both sides carry that slack, so "misses" is never
+// said wrongly, and a draw of exactly 0 (flight +inf) misses.  For a thin medium this spares nearly every ray the f64
+// logarithm and the two f64 divisions.
+DEV bool fast_medium_misses(const FastMedium& M, float a, uint32_t k0, uint32_t k1, uint32_t bounce, float best_t) {
+    const float xi = (float)medium_xi_salted(k0, k1, bounce, M.salt);
+    const float flight_lo = M.inv_density_lo * (__builtin_amdgcn_logf(xi) * -0.69314647f - 2e-7f);  // (ln 2 rounded down a little)
+    const float inside_hi = best_t * __builtin_amdgcn_rsqf(a) * 1.000002f;
+    return flight_lo > inside_hi;
+}
+#ifndef SETTLED_WAVES
+#define SETTLED_WAVES 4
+#endif
+template <bool NESTED, bool FAST>
+__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETTLED_WAVES))) void k_settled(
+    Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out, rtk::Queues q, uint32_t bounce, float4* __restrict__ radiance,
+    unsigned long long* stats, uint32_t REFILL, uint32_t min_run, uint32_t DRAIN, uint32_t near_hits, uint32_t slow_min) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // only the staged tables
+    __shared__ FastLds fl;
+    Scene St = S;
+    St.stack_cap = 0;
+    const LdsTables L = stage_tables(St, stack);
+    const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
+    const uint32_t n = q.counts[(3u + bounce % 3u) * rtk::NSHARD + shard];
+    uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
+    uint32_t* out_settled = q.counts + (3u + (bounce + 1u) % 3u) * rtk::NSHARD + shard;
+    const uint32_t shard_base = shard * q.cap_shard, lane = threadIdx.x & 63u;
+    const uint32_t medium0 = HIT_MEDIUM_BIT | S.media[0];
+    const uint32_t near_prim = (S.near0_ball && S.near0_n == 1u && near_hits) ? S.media[S.n_media] : 0x7FFFFFFFu;
+    if (FAST) {
+        if (threadIdx.x < S.n_media) {
+            const uint32_t g = S.media[threadIdx.x];
+            const Group& G = S.groups[g];
+            const float4 sph = *reinterpret_cast<const float4*>(S.prims + (G.root_ref & 0x03FFFFFFu));
+            const Material& M = S.mats[G.mat];
+            FastMedium& F = fl.m[threadIdx.x];
+            F.cx = sph.x;
+            F.cy = sph.y;
+            F.cz = sph.z;
+            F.r = sph.w;
+            F.neg_inv_density = G.neg_inv_density;
+            F.salt = medium_salt(G.order);
+            F.hit = HIT_MEDIUM_BIT | g;
+            F.key = MEDIUM_KEY_BASE + G.order;
+            F.col[0] = M.albedo[0];
+            F.col[1] = M.albedo[1];
+            F.col[2] = M.albedo[2];
+            F.inv_density_lo = (float)(-G.neg_inv_density) * 0.9999995f;
+            if (threadIdx.x == 0u)
+                for (int k = 0; k < 3; k++) {
+                    fl.blo[k] = G.blo[k];
+                    fl.bhi[k] = G.bhi[k];
+                }
+        }
+        if (threadIdx.x == 64u) {
+            float4 sph = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float ior = 1.0f;
+            uint32_t same = 0u;
+            if (S.near0_n == 1u) {
+                const float4* rec = reinterpret_cast<const float4*>(S.prims + S.media[S.n_media]);
+                sph = rec[0];
+                ior = S.mats[__float_as_uint(rec[1].y) >> 8].ior;
+                const float4 b = *reinterpret_cast<const float4*>(S.prims + (S.groups[S.media[0]].root_ref & 0x03FFFFFFu));
+                same = (__float_as_uint(b.x) == __float_as_uint(sph.x) && __float_as_uint(b.y) == __float_as_uint(sph.y) &&
+                        __float_as_uint(b.z) == __float_as_uint(sph.z) && __float_as_uint(b.w) == __float_as_uint(sph.w)) ? 1u : 0u;
+            }
+            fl.ncx = sph.x;
+            fl.ncy = sph.y;
+            fl.ncz = sph.z;
+            fl.nr = sph.w;
+            fl.near_ior = ior;
+            fl.same_sphere = same;
+        }
+        __syncthreads();
+    }
+    // runs of at least min_run paths: a wave refills from its own run only, and a short run ends in a long, thin drain
+    const uint32_t nw = stride * (rtk::BLOCK / 64u), wi = j0 * (rtk::BLOCK / 64u) + (threadIdx.x >> 6);
+    uint32_t per = (((n + nw - 1u) / nw) + 63u) & ~63u;
+    if (per < min_run) per = min_run;
+    const unsigned long long first = (unsigned long long)wi * per;
+    uint32_t next = __builtin_amdgcn_readfirstlane(first < n ? (uint32_t)first : n);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(n - next > per ? next + per : n);
+    // a lane: have = it holds a path whose next hit is settled (p.settled != 0); leaving = it holds one that has to go back
+    // to the tree (waits for the wave's next refill)
+    bool have = false, leaving = false;
+    PathRegs p;
+    p.o = p.d = p.T = mk3(0.0f, 0.0f, 0.0f);
+    p.time = 0.0f;
+    p.k0 = p.k1 = p.slot = 0u;
+    uint32_t rays = 0;
+    const uint32_t drain = bounce + 1u >= rc.max_depth ? 1u : DRAIN;
+#ifdef RT_SECTIONS  // wave cycles per section of the loop (s_memtime), summed into stats[24..28]; [29] counts loop rounds
+    unsigned long long cyc[5] = {0, 0, 0, 0, 0}, rounds = 0, t0 = 0, t1 = 0;
+#define RT_SECTION(k, ...) do { asm volatile("" :: __VA_ARGS__); t1 = __builtin_amdgcn_s_memtime(); cyc[k] += t1 - t0; t0 = t1; } while (0)
+#else
+#define RT_SECTION(k, ...) do { } while (0)
+#endif
+    if (next < end) {
+        for (;;) {
+#ifdef RT_SECTIONS
+            t0 = __builtin_amdgcn_s_memtime();
+            rounds++;
+#endif
+            const unsigned long long busy = __ballot(have);
+            const uint32_t n_idle = 64u - (uint32_t)__popcll(busy);
+            const bool more = next < end;
+            // Once its run is used up a wave does not drain to the last path (a few lanes for up to max_depth rounds): with
+            // fewer than DRAIN paths left it hands them on, still settled, to the far end of `out`, where the next launch of
+            // this kernel finds them next to the paths k_shade has settled meanwhile.  (Not in the last launch of a batch, which
+            // nothing follows: there every path is at the depth limit and ends with its next step.)
+            if ((!more && n_idle > 64u - drain) || (more && n_idle >= REFILL)) {
+                const unsigned long long out_mask = __ballot(leaving);
+                if (out_mask) {
+                    uint32_t at = 0;
+                    if (lane == 0u) at = atomicAdd(out_count, (uint32_t)__popcll(out_mask));
+                    at = __builtin_amdgcn_readfirstlane(at);
+                    if (leaving) {
+                        p.settled = 0.0f;
+                        store_path(out, shard_base + at + lane_prefix(out_mask), p);
+                        leaving = false;
+                    }
+                }
+                if (!more) {
+                    if (busy) {
+                        uint32_t at = 0;
+                        if (lane == 0u) at = atomicAdd(out_settled, 64u - n_idle);
+                        at = __builtin_amdgcn_readfirstlane(at);
+                        if (have) {
+                            const uint32_t to = shard_base + q.cap_shard - 1u - (at + lane_prefix(busy));
+                            store_path(out, to, p);
+                            out.settled[to] = p.settled;
+                        }
+                    }
+                    break;
+                }
+                const uint32_t mine = next + lane_prefix(~busy);
+                next += n_idle;
+                if (!have && mine < end) {
+                    const uint32_t at = shard_base + q.cap_shard - 1u - mine;
+                    load_path(in, at, p);
+                    p.settled = in.settled[at];
+                    have = true;
+                }
+            }
+            RT_SECTION(0, "v"(p.o.x), "v"(p.d.x), "v"(p.T.x), "v"(p.k0), "v"(p.settled));
+            // FAST: every path is stepped here; the general step below runs only in kernels compiled without it
+            bool general = have && !FAST;
+            if (FAST) {
+                // the hit at the stored distance -- in the first medium, or on the glass near it -- unless a later medium takes the
+                // ray first.  Nearly always none does and the draw alone says so (fast_medium_misses); the few lanes that need the
+                // real test wait until `slow_min` of their wave do, or nothing else is left to do: run for one or two lanes in
+                // every round, the f64 arithmetic would cost the round a quarter of its time.
+                float t = __builtin_fabsf(p.settled);
+                uint32_t which = p.settled > 0.0f ? 0u : 4u;  // 0..3: that medium; 4: the sphere near the first medium
+                const float a = dot3(p.d, p.d);
+                bool clear = have;
+                for (uint32_t m = 1u; m < S.n_media; m++) clear = clear && fast_medium_misses(fl.m[m], a, p.k0, p.k1, p.bounce, t);
+                const unsigned long long wait_mask = __ballot(have && !clear);
+                if (wait_mask && ((uint32_t)__popcll(wait_mask) >= slow_min || __ballot(clear) == 0ull || next >= end)) {
+                    // (never left waiting once the wave's run is used up: a path must not be handed on to the next launch
+                    // without having made a step in this one -- every path of launch L is at bounce L at least, and the last
+                    // launch ends them all)
+                    if (have && !clear) {
+                        for (uint32_t m = 1u; m < S.n_media; m++) {
+                            float tm;
+                            if (fast_medium(fl.m[m], p.o, p.d, a, 0.005f, p.k0, p.k1, p.bounce, t, tm)) {
+                                t = tm;
+                                which = m;
+                            }
+                        }
+                        clear = true;
+                    }
+                }
+                RT_SECTION(1, "v"(t), "v"(which));
+                if (clear) {
+                    rays++;
+                    const f3 point = p.o + (t * p.d);
+                    Rng rng{p.k0, p.k1, p.bounce << 24};
+                    f3 att{1.0f, 1.0f, 1.0f}, dir;
+                    if (which < 4u) {  // shade_path for a medium with a plain colour (shapes.rs:690-697, materials.rs:204-215)
+                        dir = normalize3(rand_in_unit_sphere(rng));
+                        att = mk3(fl.m[which].col[0], fl.m[which].col[1], fl.m[which].col[2]);
+                    } else {  // ... and for a sphere of glass (make_record: shapes.rs:141-153, hit_record.rs:32-42; materials.rs:117-148)
+                        Record rec;
+                        const f3 outward = (point - mk3(fl.ncx, fl.ncy, fl.ncz)) / fl.nr;
+                        rec.front = dot3(p.d, outward) < 0.0f;
+                        rec.normal = rec.front ? outward : -outward;
+                        rec.point = point;
+                        rec.u = rec.v = 0.0f;
+                        Material M;
+                        M.kind = MK_DIELECTRIC;
+                        M.ior = fl.near_ior;
+                        M.fuzz = 0.0f;
+                        M.tex = M.pad = 0u;
+                        M.albedo[0] = M.albedo[1] = M.albedo[2] = 0.0f;
+                        (void)scatter(M, att, p.d, rec, rng, att, dir);  // (always goes on, attenuation 1)
+                    }
+                    if (p.bounce + 1u >= rc.max_depth) {  // main.rs:45-47: the next ray_color call returns zero
+                        end_path(rc, radiance, p.slot, mk3(0.0f, 0.0f, 0.0f));
+                        have = false;
+                    } else {
+                        p.T = p.T * att;
+                        p.o = point;
+                        p.d = dir;
+                        p.bounce++;
+                    }
+                    RT_SECTION(2, "v"(p.o.x), "v"(p.d.x), "v"(p.T.x));
+                    if (have) {
+                        // settle_next with the records in LDS
+                        const f3 c0 = mk3(fl.m[0].cx, fl.m[0].cy, fl.m[0].cz);
+                        const float rr = fl.m[0].r * 1.0005f;
+                        const f3 oc = p.o - c0;
+                        const bool inside = p.o.x >= fl.blo[0] && p.o.x <= fl.bhi[0] && p.o.y >= fl.blo[1] && p.o.y <= fl.bhi[1] &&
+                                            p.o.z >= fl.blo[2] && p.o.z <= fl.bhi[2] && dot3(oc, oc) <= rr * rr;
+                        float s = 0.0f;
+                        if (inside) {
+                            const float a2 = dot3(p.d, p.d);
+                            float q0, q1, tg = INF_F, tm;
+                            const bool line_hits = sphere_roots(c0, fl.m[0].r, p.o, p.d, a2, q0, q1);
+                            bool hit_g = false;
+                            if (S.near0_n == 1u) {
+                                // (the same sphere: its roots are the boundary's -- quotient_pair gives the quotients of
+                                // sphere_candidate bit for bit -- and the root it takes is pick_root's)
+                                if (fl.same_sphere) hit_g = pick_root(line_hits ? 3u : 0u, q0, q1, 0.005f, INF_F, tg);
+                                else hit_g = sphere_candidate(mk3(fl.ncx, fl.ncy, fl.ncz), fl.nr, p.o, p.d, a2, 0.005f, INF_F, tg);
+                            }
+                            if (fast_medium_flight(fl.m[0], line_hits, q0, q1, a2, 0.005f, p.k0, p.k1, p.bounce, hit_g ? tg : INF_F, tm)) {
+                                if (tm > 0.0f) s = tm;
+                            } else if (hit_g && tg > 0.0f && near_prim != 0x7FFFFFFFu) {
+                                const f3 pc = (p.o + tg * p.d) - c0;
+                                if (dot3(pc, pc) <= rr * rr) s = -tg;
+                            }
+                        }
+                        p.settled = s;
+                        have = s != 0.0f;
+                        leaving = !have;
+                    }
+                    RT_SECTION(3, "v"(p.settled));
+                }
+            }
+            if (general) {
+                Hit h;  // (> 0: the first medium at that distance; < 0: the one primitive near it)
+                h.t = __builtin_fabsf(p.settled);
+                h.prim = p.settled > 0.0f ? medium0 : near_prim;
+                h.grp = -1;
+                h.key = 0;
+                for (uint32_t m = 1u; m < S.n_media; m++)
+                    test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, p.bounce, h);
+                RT_SECTION(1, "v"(h.t), "v"(h.prim));
+                rays++;
+                have = false;
+                const bool alive = shade_path<NESTED>(S, L, rc, p, h, p.bounce, radiance);
+                RT_SECTION(2, "v"(p.o.x), "v"(p.d.x), "v"(p.T.x));
+                if (alive) {
+                    p.settled = settle_next<NESTED>(S, p, medium0, near_prim);
+                    have = p.settled != 0.0f;
+                    leaving = !have;
+                }
+                RT_SECTION(3, "v"(p.settled));
+            }
+        }
+    }
+#ifdef RT_SECTIONS
+    if (lane == 0u && rounds) {
+        for (int k = 0; k < 4; k++) atomicAdd(stats + 24 + k, cyc[k]);
+        atomicAdd(stats + 29, rounds);
+    }
+#endif
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if (lane == 0u && rays) {
+        atomicAdd(stats, (unsigned long long)rays);
+        atomicAdd(stats + 16, (unsigned long long)rays);
     }
 }
 
@@ -648,7 +961,7 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_finish(Scene S, rtk::RenderConst
     for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n + n_settled; i += stride * rtk::BLOCK) {
         PathRegs p;
         load_path(in, shard_base + (i < n ? i : q.cap_shard - 1u - (i - n)), p);
-        for (uint32_t b = bounce;; b++) {  // shade_path ends the path at the depth limit at the latest
+        for (uint32_t b = p.bounce;; b++) {  // (the path's own bounce number; shade_path ends the path at the depth limit at the latest)
             Hit h;
             trace_ray<rtk::BLOCK, GROUPS, FLAT, false>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, b, h, stk, overflow_flag, nullptr);
             rays++;
@@ -868,19 +1181,7 @@ inline int grid_flat(unsigned long long n) {
 // once next to rays that walk the whole tree), and blocks own fixed strides of tiles, so many short blocks
 // balance far better than one round of long ones: measured gains level off near 16.  The trace kernel of the
 // split pipeline balances inside each wave instead and wants long runs per wave: 2.
-int env_factor(const char* name, int dflt) {
-    const char* e = getenv(name);
-    int k = e ? atoi(e) : dflt;
-    return k < 1 ? 1 : (k > 64 ? 64 : k);
-}
-int oversubscription() {
-    static const int v = env_factor("RTAMD_OVERSUB", 16);
-    return v;
-}
-int trace_oversubscription() {
-    static const int v = env_factor("RTAMD_TRACE_OVERSUB", 2);
-    return v;
-}
+// (the factors come from rtk::Tuning: oversub, trace_oversub)
 // Blocks of kernel `fn` that are resident at once on the current device.
 uint32_t resident_blocks(const void* fn, size_t smem) {
     static std::mutex mu;
@@ -943,31 +1244,30 @@ inline size_t table_bytes(const Scene& scene) {
            (scene.lds_scene ? 32u * (size_t)(scene.n_prims + scene.n_mats + scene.n_texs) : 0);
 }
 
-hipError_t launch_raygen(hipStream_t s, const RenderConst& rc, const Batch& batch, PathState out, Queues q) {
+hipError_t launch_raygen(hipStream_t s, const Tuning& tn, const RenderConst& rc, const Batch& batch, PathState out, Queues q) {
     unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
     uint32_t bps = (uint32_t)((n + (unsigned long long)BLOCK * NSHARD - 1) / ((unsigned long long)BLOCK * NSHARD));
-    hipLaunchKernelGGL(k_raygen, dim3(grid_sharded(bps, (const void*)&k_raygen, oversubscription())), dim3(BLOCK), 0, s, rc, batch, out, q);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_sharded(bps, (const void*)&k_raygen, tn.oversub)), dim3(BLOCK), 0, s, rc, batch, out, q);
     return hipGetLastError();
 }
 
 // Entries of the traversal stack k_trace keeps in LDS; deeper entries spill to global memory.  The walk takes
 // the near child first, so a ray rarely holds more than a few entries, while LDS sized for the worst case
 // (tree depth) is what limits the resident waves of this latency-bound kernel.
-uint32_t trace_lds_entries(const Scene& scene) {
-    static const int v = env_factor("RTAMD_STACK_LDS", 8);
-    return std::min<uint32_t>(std::max(1u, scene.stack_cap), (uint32_t)v);
+uint32_t trace_lds_entries(const Tuning& tn, const Scene& scene) {
+    return std::min<uint32_t>(std::max(1u, scene.stack_cap), (uint32_t)std::max(1, tn.stack_lds));
 }
-hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, PathState in, Queues q, uint32_t bounce,
+hipError_t launch_trace(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, const Scene& scene, PathState in, Queues q, uint32_t bounce,
                         uint32_t blocks_per_shard, float4* hits, unsigned long long* stats, uint32_t* overflow_flag,
                         SpillArea& spill) {
     const dim3 block(BLOCK);
-    const uint32_t lds_entries = trace_lds_entries(scene);
+    const uint32_t lds_entries = trace_lds_entries(tn, scene);
     // stacks, then (scenes with instances) each lane's world ray
     const size_t smem = (size_t)lds_entries * BLOCK * sizeof(uint32_t) + (cfg.has_groups ? (size_t)BLOCK * 6 * sizeof(float) : 0);
     const uint32_t deep = std::max(1u, scene.stack_cap) - lds_entries;
     // A wave refills its free lanes from its own run of the queue, so a run of one tile gives it nothing to refill
     // from.  When few rays are queued, launch fewer blocks rather than shorter runs: at least min_run rays per wave.
-    static const int min_run = env_factor("RTAMD_TRACE_MIN_RUN", 16) * 8;  // in units of 8 rays (env_factor caps at 64)
+    const int min_run = std::max(8, tn.trace_min_run);
     blocks_per_shard = std::max(1u, (blocks_per_shard * BLOCK + (BLOCK / 64) * min_run - 1) / ((BLOCK / 64) * min_run));
 #define RT_CALL(G, C, F)                                       \
     do {                                                       \
@@ -976,7 +1276,7 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
     } while (0)
 #define RT_TRACE(G, C, F, W)                                                                                                     \
     do {                                                                                                                         \
-        const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C, F, W>, trace_oversubscription(), smem);      \
+        const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C, F, W>, tn.trace_oversub, smem);      \
         const size_t need = (size_t)deep * grid * BLOCK * sizeof(uint32_t);                                                      \
         if (need > spill.bytes) {                                                                                                \
             if (spill.p) (void)hipFree(spill.p);                                                                                 \
@@ -987,7 +1287,7 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
             spill.bytes = need;                                                                                                  \
         }                                                                                                                        \
         hipLaunchKernelGGL((k_trace<G, C, F, W>), dim3(grid), block, smem, s, scene, in, q, bounce, hits, stats, overflow_flag,  \
-                           (uint32_t)env_factor("RTAMD_REFILL", 24), env_factor("RTAMD_INNER_STEPS", 4), lds_entries,            \
+                           (uint32_t)tn.refill, tn.inner_steps, lds_entries,                                                     \
                            (uint32_t*)spill.p);                                                                                  \
     } while (0)
     RT_DISPATCH_TRACE_CFG(cfg, scene.flat != 0u, RT_CALL);
@@ -996,16 +1296,18 @@ hipError_t launch_trace(hipStream_t s, const TraceCfg& cfg, const Scene& scene, 
     return hipGetLastError();
 }
 
-hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc, PathState in, PathState out,
+bool scene_settles(const Scene& scene) { return scene.n_media != 0u && scene.near0_n != NEAR_NONE; }
+
+hipError_t launch_shade(hipStream_t s, const Tuning& tn, const Scene& scene, const RenderConst& rc, PathState in, PathState out,
                         const float4* hits, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
                         unsigned long long* stats, bool may_settle) {
     const size_t smem = table_bytes(scene);
     // lanes of a wave that have to qualify for its paths to be settled ahead (see k_shade)
-    static const uint32_t entry_lanes = std::min(64u, std::max(1u, getenv("RTAMD_SETTLE_ENTRY") ? (uint32_t)atoi(getenv("RTAMD_SETTLE_ENTRY")) : 8u));
-    const bool settle = may_settle && scene.n_media != 0u && scene.near0_n != NEAR_NONE;
-    static const uint32_t near_hits = getenv("RTAMD_SETTLE_NEAR_HITS") ? (uint32_t)atoi(getenv("RTAMD_SETTLE_NEAR_HITS")) : 1u;
+    const uint32_t entry_lanes = std::min(64u, std::max(1u, tn.settle_entry));
+    const bool settle = may_settle && scene_settles(scene);
+    const uint32_t near_hits = tn.settle_near_hits;
 #define RT_SHADE(N, T)                                                                                                              \
-    hipLaunchKernelGGL((k_shade<N, T>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<N, T>, oversubscription(), smem)), \
+    hipLaunchKernelGGL((k_shade<N, T>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<N, T>, tn.oversub, smem)), \
                        dim3(BLOCK), smem, s, scene, rc, in, out, hits, q, bounce, radiance, stats, entry_lanes, near_hits)
     if (scene.nested) {
         if (settle) RT_SHADE(true, true);
@@ -1018,7 +1320,26 @@ hipError_t launch_shade(hipStream_t s, const Scene& scene, const RenderConst& rc
     return hipGetLastError();
 }
 
-hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, const Batch& batch,
+hipError_t launch_settled(hipStream_t s, const Tuning& tn, const Scene& scene, const RenderConst& rc, PathState in, PathState out, Queues q,
+                          uint32_t bounce, float4* radiance, unsigned long long* stats) {
+    const size_t smem = table_bytes(scene);
+    const uint32_t refill = (uint32_t)std::min(64, std::max(1, tn.settled_refill));
+    const uint32_t min_run = (uint32_t)std::max(64, tn.settled_min_run) & ~63u;
+    const uint32_t drain = (uint32_t)std::min(64, std::max(1, tn.settled_drain));
+    // persistent waves: as many blocks as are resident at once (times settled_oversub); the kernel cuts the far end of every
+    // shard into one run per wave and gives waves beyond the last run nothing
+    const uint32_t slow_min = (uint32_t)std::min(64, std::max(1, tn.settled_slow_min));
+#define RT_SETTLED(N, F)                                                                                                                      \
+    hipLaunchKernelGGL((k_settled<N, F>), dim3(grid_sharded(MAX_BLOCKS_PER_SHARD, (const void*)&k_settled<N, F>, tn.settled_oversub, smem)), \
+                       dim3(BLOCK), smem, s, scene, rc, in, out, q, bounce, radiance, stats, refill, min_run, drain, tn.settle_near_hits, slow_min)
+    if (scene.nested) RT_SETTLED(true, false);
+    else if (scene.settle_fast && tn.settled_fast) RT_SETTLED(false, true);
+    else RT_SETTLED(false, false);
+#undef RT_SETTLED
+    return hipGetLastError();
+}
+
+hipError_t launch_bounce(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, const Batch& batch,
                          PathState in, PathState out, Queues q, uint32_t bounce, uint32_t blocks_per_shard, float4* radiance,
                          unsigned long long* stats, uint32_t* overflow_flag) {
     const dim3 block(BLOCK);
@@ -1026,14 +1347,14 @@ hipError_t launch_bounce(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
     if (bounce == 0) {
 #define RT_CALL(G, C, F)                                                                                                  \
     hipLaunchKernelGGL((k_bounce<G, C, true, F>),                                                                         \
-                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, true, F>, oversubscription(), smem)), block, \
+                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, true, F>, tn.oversub, smem)), block, \
                        smem, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
         RT_DISPATCH_TRACE_CFG(cfg, scene.flat != 0u, RT_CALL);
 #undef RT_CALL
     } else {
 #define RT_CALL(G, C, F)                                                                                                   \
     hipLaunchKernelGGL((k_bounce<G, C, false, F>),                                                                         \
-                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, false, F>, oversubscription(), smem)), block, \
+                       dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, false, F>, tn.oversub, smem)), block, \
                        smem, s, scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag)
         RT_DISPATCH_TRACE_CFG(cfg, scene.flat != 0u, RT_CALL);
 #undef RT_CALL
@@ -1062,15 +1383,15 @@ hipError_t launch_finish(hipStream_t s, const TraceCfg& cfg, const Scene& scene,
     return hipGetLastError();
 }
 
-hipError_t launch_paths(hipStream_t s, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, const Batch& batch,
+hipError_t launch_paths(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, const Scene& scene, const RenderConst& rc, const Batch& batch,
                         float4* radiance, unsigned long long* stats, uint32_t* overflow_flag) {
     const size_t smem = stack_bytes(scene) + table_bytes(scene);
     const unsigned long long n = (unsigned long long)batch.npix * batch.n_samples;
-    const uint32_t regen = (uint32_t)env_factor("RTAMD_REGEN", 8);
+    const uint32_t regen = (uint32_t)std::min(64, std::max(1, tn.regen));
     // Grid: runs of about 1536 path slots per wave, but never fewer blocks than fit on the chip at once.  Runs differ a
     // lot in cost (sky next to glass) and the block scheduler balances them, so short runs are good -- until a run is
     // so short that the lanes idling while its last paths drain (up to max_depth bounces) weigh against it.
-    static const unsigned long long run = 24ull * (unsigned long long)env_factor("RTAMD_PATHS_RUN", 64);  // units of 24 slots
+    const unsigned long long run = (unsigned long long)std::max(24, tn.paths_run);
     const unsigned long long want = (n + (BLOCK / 64) * run - 1) / ((BLOCK / 64) * run);
 #define RT_PATHS(G, F)                                                                                                      \
     do {                                                                                                                    \

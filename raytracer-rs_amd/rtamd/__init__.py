@@ -66,7 +66,8 @@ class rt_render_stats(C.Structure):
                 ("shade_launches", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
                 ("bounce_ms", C.c_double), ("bounce_kernel_launches", C.c_uint64), ("pipeline", C.c_uint32),
                 ("tail_launches", C.c_uint32), ("tail_rays", C.c_uint64), ("tail_ms", C.c_double),
-                ("paths_ms", C.c_double), ("paths_launches", C.c_uint64), ("settled_rays", C.c_uint64)]
+                ("paths_ms", C.c_double), ("paths_launches", C.c_uint64), ("settled_rays", C.c_uint64),
+                ("settled_ms", C.c_double), ("settled_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -26,7 +26,7 @@ for arg in sys.argv[1:]:
             best = (dt, st)
     dt, st = best
     print(f"{tag:14s} {name:18s} {spp:4d} spp {dt*1e3:8.2f} ms {st['rays']/dt/1e6:8.1f} Mrays/s | trace {st['trace_ms']:7.2f} shade {st['shade_ms']:7.2f} "
-          f"bounce {st['bounce_ms']:7.2f} tail {st['tail_ms']:5.2f} paths {st['paths_ms']:7.2f} | sum {acc.sum().item():.6e}", flush=True)
+          f"settled {st.get('settled_ms', 0.0):7.2f} bounce {st['bounce_ms']:7.2f} tail {st['tail_ms']:5.2f} paths {st['paths_ms']:7.2f} | rays {st['rays']} settled {st['settled_rays']} | sum {acc.sum().item():.6e}", flush=True)
     if os.environ.get("VISITS") == "1":
         ctx.profile(events=False, count_visits=True)
         _, sv = ctx.render(w, h, cam, 4, accum=acc)

@@ -523,23 +523,35 @@ def test_tail_kernel_changes_no_bit(name):
 @pytest.mark.parametrize("name", ["final_scene", "medium_cluster"])
 def test_settling_the_first_medium_ahead_changes_no_bit(name, monkeypatch):
     """k_shade may find out for the ray it has just made that the first medium takes it (primitives near the boundary, then
-    the medium's own test) and queue the path where the trace kernel does not look.  The answer is the one the next bounce
-    would have found after the tree walk, so image and ray count must not change: with the paths joining from one lane per
-    wave on, with the default, and with the tail kernel taking over queues that hold such paths."""
+    the medium's own test) and queue the path where the trace kernel does not look; k_settled then follows such paths in
+    registers, bounce after bounce, for as long as their next hit can be settled the same way.  Every answer is the one the
+    next bounce would have found after the tree walk, so image and ray count must not change: with the paths joining from one
+    lane per wave on, with the default, with the step specialised for sphere-shaped media off (final_scene qualifies for it,
+    medium_cluster does not), with its waiting lanes served at once or only in large groups, with short runs and early
+    hand-over between launches, and with the tail kernel taking over queues that hold such paths."""
     w, h, spp = 200, 200, 24
     out = []
-    for settle, entry, tail in (("0", "8", 0), ("1", "1", 0), ("1", "8", 0), ("1", "8", 20000)):
-        monkeypatch.setenv("RTAMD_SETTLE_AHEAD", settle)
-        monkeypatch.setenv("RTAMD_SETTLE_ENTRY", entry)  # (read once per process: the first value stays; the default is covered either way)
+    cases = [dict(RTAMD_SETTLE_AHEAD="0"), dict(RTAMD_SETTLE_ENTRY="1"), dict(), dict(RTAMD_SETTLED_FAST="0"),
+             dict(RTAMD_SETTLED_SLOW_MIN="1"), dict(RTAMD_SETTLED_SLOW_MIN="40", RTAMD_SETTLED_REFILL="4"),
+             dict(RTAMD_SETTLED_MIN_RUN="64", RTAMD_SETTLED_DRAIN="60"), dict(RTAMD_SETTLED_DRAIN="1", RTAMD_SETTLE_NEAR_HITS="0"),
+             dict(tail=20000)]
+    for case in cases:
+        for k in ("RTAMD_SETTLE_AHEAD", "RTAMD_SETTLE_ENTRY", "RTAMD_SETTLED_FAST", "RTAMD_SETTLED_SLOW_MIN", "RTAMD_SETTLED_REFILL",
+                  "RTAMD_SETTLED_MIN_RUN", "RTAMD_SETTLED_DRAIN", "RTAMD_SETTLE_NEAR_HITS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in case.items():
+            if k.startswith("RTAMD_"):
+                monkeypatch.setenv(k, v)  # (a context reads its knobs when it is created)
         ctx = rtamd.Context(0)
         ctx.load_scene(name, seed=1)
-        ctx.set_tail_paths(tail)
+        ctx.set_tail_paths(case.get("tail", 0))
         cam = ctx.preset_camera(w / h)
         for pipe in (0, 2):
             ctx.set_pipeline(pipe)
             img, st = ctx.render(w, h, cam, spp, seed=5)
             if name == "final_scene":  # (its first medium is the dense sphere that holds paths for many bounces)
-                assert (st["settled_rays"] > 0.1 * st["rays"]) if settle == "1" else st["settled_rays"] == 0
+                settle = case.get("RTAMD_SETTLE_AHEAD", "1") == "1"
+                assert (st["settled_rays"] > 0.1 * st["rays"]) if settle else st["settled_rays"] == 0
             out.append((img, st["rays"]))
         ctx.close()
     for img, rays in out[1:]:
