@@ -8,8 +8,8 @@ BVH, textures, pixel lists) are resident in HBM before the timed region starts.
 
 The default workload is the scene the reference binary itself renders (main.rs:353-354, 375-380):
 the Next Week final scene, 800x800, 10 000 samples per pixel, depth 50 -- the tree-walking path
-(BVHNode::intersect) the metric is about.  With one rank the same run also renders one frame each
-of BASELINE.json's configs[0..2] outside the timed steps and lists them under config.others.
+(BVHNode::intersect) the metric is about.  With one rank the same run also renders every one of
+BASELINE.json's five configs once at full size outside the timed steps and lists them under config.others.
 
   python bench.py                       # 1 GPU, default steps
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
@@ -55,7 +55,7 @@ MAX_DEPTH = 50
 PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak
 DEFAULT_WORKLOAD = "final_scene"
 # one frame each, outside the timed steps, when the default workload runs on one rank
-OTHER_CONFIGS = ("c1_random_world", "c2_textures", "c3_random_world")
+OTHER_CONFIGS = ("c1_random_world", "c2_textures", "c3_random_world", "c4_cornell", "c5_synth10m")
 
 
 def log(*a):
@@ -159,6 +159,7 @@ class Frame:
         return self.frame if self.exchange_kind != "none" else self.accum
 
 
+
 L2_PER_XCD = 4 << 20  # a scene below this stays resident in every XCD's L2 for a whole launch
 
 
@@ -237,16 +238,53 @@ def host_threads():
     return max(1, n)
 
 
+ORACLE_FAST_FLAGS = ("-O3 -fno-semantic-interposition -ftls-model=initial-exec -DRT_ORACLE_FAST -std=c++17 -fPIC -ffp-contract=off "
+                     "-fno-fast-math -pthread")
+
+
+def oracle_for_this_host():
+    """(library path, flags) of the oracle build to time.  The committed fast build (oracle/liboracle_fast.so) targets a
+    generic AVX2 server because it is compiled in one container and run on another host; when a compiler is at hand
+    the same source is rebuilt here with -march=native, as BASELINE.md describes the CPU baseline.  The rebuilt library
+    must reproduce the checker build's image bit for bit on a small frame, else the committed one is used."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import shutil
+    import subprocess
+    import tempfile
+    import orc
+    fallback = (orc._FAST_PATH, "-march=x86-64-v3 " + ORACLE_FAST_FLAGS + " (oracle/Makefile, built ahead of the run)")
+    cxx = shutil.which("g++")
+    if not cxx:
+        return fallback
+    try:
+        out = Path(tempfile.mkdtemp(prefix="rt_oracle_native_")) / "liboracle_native.so"
+        cmd = [cxx, "-march=native", *ORACLE_FAST_FLAGS.split(), "-shared", "-o", str(out), str(ROOT / "oracle" / "rt_oracle.cpp")]
+        subprocess.run(cmd, check=True, timeout=300, capture_output=True)
+        a, b = orc.Scene("final_scene", seed=1), orc.Scene("final_scene", seed=1, lib_path=out)
+        img_a, rays_a = a.render(48, 48, 1.0, 2, depth=MAX_DEPTH, seed=1, mode=1)
+        img_b, rays_b = b.render(48, 48, 1.0, 2, depth=MAX_DEPTH, seed=1, mode=1)
+        a.close()
+        b.close()
+        if rays_a != rays_b or not np.array_equal(img_a, img_b):
+            log("cpu_baseline: the -march=native oracle differs from the checker build; timing the committed fast build instead")
+            return fallback
+        return out, "-march=native " + ORACLE_FAST_FLAGS + " (rebuilt on this host)"
+    except Exception as e:  # no compiler, no temp dir, a time limit: the committed build is timed
+        log(f"cpu_baseline: could not rebuild the oracle for this host ({type(e).__name__}); timing the committed fast build")
+        return fallback
+
+
 def cpu_baseline(frames_cfg, width, aspect, seconds_target=20.0):
     """The CPU oracle (a port of the reference; the Rust binary cannot be built here) on a bounded sample of the
     same workload: the same frames at full resolution and one reduced sample count for all of them, the
     reference's own structure (pointer BVH, always-left-then-right walk, one pixel per task), on every host
-    thread this process may use."""
+    thread this process may use.  The program timed is the -O3 build without the checker's visit counters."""
     sys.path.insert(0, str(ROOT / "tests"))
     import orc
+    lib_path, flags = oracle_for_this_host()
     threads = host_threads()
     h = rtamd.image_height(width, aspect)
-    scenes = [orc.Scene(name, seed=1) for name in frames_cfg]
+    scenes = [orc.Scene(name, seed=1, lib_path=lib_path) for name in frames_cfg]
     rays_total, sec_total = 0, 0.0
     for sc in scenes:  # one sample per pixel of every frame: sizes the rest
         t0 = time.perf_counter()
@@ -264,7 +302,9 @@ def cpu_baseline(frames_cfg, width, aspect, seconds_target=20.0):
         sc.close()
     return {"value": rays_total / sec_total / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{'+'.join(frames_cfg)} at {width}x{h}, {spp} spp each, depth {MAX_DEPTH}, "
-                      f"oracle BVHNode path (oracle/rt_oracle.cpp), {sec_total:.1f} s"}
+                      f"oracle BVHNode path (oracle/rt_oracle.cpp built {flags}), {sec_total:.1f} s on {threads} threads = "
+                      f"this process's CPU affinity mask capped by OMP_NUM_THREADS, not the core count of the machine "
+                      f"({os.cpu_count()} logical CPUs)"}
 
 
 def pmc_profile(workload, kernel, width=0, spp=0):
@@ -288,8 +328,8 @@ def kernel_rooflines(frames, stats, steps, workload, use_committed, width=0, spp
     fits one XCD's L2 is charged once per XCD and launch, a larger one per node fetch and primitive test, and where
     that exceeds what HBM can deliver (upper tree levels served by L2 / Infinity Cache) the committed measured
     traffic takes its place, so that no fraction above 1 is ever reported."""
-    sums = {k: sum(st[k] for s in stats for st in s) for k in ("trace_ms", "shade_ms", "bounce_ms", "tail_ms", "paths_ms")}
-    tr_bytes = sh_bytes = bo_bytes = pa_bytes = 0.0
+    sums = {k: sum(st.get(k, 0.0) for s in stats for st in s) for k in ("trace_ms", "shade_ms", "bounce_ms", "tail_ms", "paths_ms", "settled_ms")}
+    tr_bytes = sh_bytes = bo_bytes = pa_bytes = se_bytes = 0.0
     for f, st_frame in zip(frames, zip(*stats)):
         # per-ray node fetches / primitive tests of this frame: one instrumented pass at 1 spp (untimed)
         f.ctx.profile(events=False, count_visits=True)
@@ -315,14 +355,19 @@ def kernel_rooflines(frames, stats, steps, workload, use_committed, width=0, spp
             bo_bytes += fused_rays * bounce_bytes_per_ray(f.info, primary, alive, nodes_pr, prims_pr)
             bo_bytes += scene_bytes_per_launch(f.info) * sum(s["bounce_kernel_launches"] for s in st_frame)
         if split_rays:
-            # (rays settled by the bounce before them go from k_shade to k_shade: the trace kernel never reads them)
-            walked_rays = split_rays - sum(s.get("settled_rays", 0) for s in st_frame)
+            # (rays whose hit the bounce before them has settled are followed by k_settled in registers: neither the trace
+            # kernel nor k_shade sees them; k_settled moves a queue entry in -- 56 B of state + 4 B of distance -- and,
+            # for about as many paths, 56 B out when the path goes back to the tree)
+            settled_rays = sum(s.get("settled_rays", 0) for s in st_frame)
+            walked_rays = split_rays - settled_rays
             tr_bytes += walked_rays * trace_bytes_per_ray(f.info, nodes_pr, prims_pr)
             tr_bytes += scene_bytes_per_launch(f.info) * sum(s["trace_launches"] for s in st_frame)
-            sh_bytes += split_rays * shade_bytes_per_ray(alive)
-    launches = {k: sum(st[k] for s in stats for st in s) for k in ("trace_launches", "shade_launches", "bounce_kernel_launches", "paths_launches")}
+            sh_bytes += walked_rays * shade_bytes_per_ray(alive)
+            se_bytes += sum(s.get("settled_entries", 0) for s in st_frame) * (60.0 + 56.0)
+    launches = {k: sum(st.get(k, 0) for s in stats for st in s) for k in ("trace_launches", "shade_launches", "bounce_kernel_launches", "paths_launches", "settled_launches")}
     cands = [("k_trace", sums["trace_ms"], tr_bytes, launches["trace_launches"]), ("k_shade", sums["shade_ms"], sh_bytes, launches["shade_launches"]),
-             ("k_bounce", sums["bounce_ms"], bo_bytes, launches["bounce_kernel_launches"]), ("k_paths", sums["paths_ms"], pa_bytes, launches["paths_launches"])]
+             ("k_bounce", sums["bounce_ms"], bo_bytes, launches["bounce_kernel_launches"]), ("k_paths", sums["paths_ms"], pa_bytes, launches["paths_launches"]),
+             ("k_settled", sums["settled_ms"], se_bytes, launches["settled_launches"])]
 
     def one(name, ms, nbytes, nl):
         t = measured_traffic(workload, name, width, spp) if use_committed else None
@@ -360,8 +405,23 @@ def kernel_rooflines(frames, stats, steps, workload, use_committed, width=0, spp
             "scene_resident_in_l2": all(f.info["device_bytes"] <= L2_PER_XCD for f in frames),
             "trace_ms_per_step": round(sums["trace_ms"] / steps, 3), "shade_ms_per_step": round(sums["shade_ms"] / steps, 3),
             "bounce_ms_per_step": round(sums["bounce_ms"] / steps, 3), "tail_ms_per_step": round(sums["tail_ms"] / steps, 3),
-            "paths_ms_per_step": round(sums["paths_ms"] / steps, 3),
+            "paths_ms_per_step": round(sums["paths_ms"] / steps, 3), "settled_ms_per_step": round(sums["settled_ms"] / steps, 3),
             "nodes_per_ray": [round(f.nodes_per_ray, 2) for f in frames], "prims_per_ray": [round(f.prims_per_ray, 2) for f in frames]}
+    # The two whole-step figures of the survey's measurement plan, over ALL kernels and the step's wall time: every ray
+    # charged 32 B per node visit + 32 B per primitive test + 128 B of path state (served by L1/L2 for a resident scene, so
+    # not an HBM figure), and the compulsory part alone, 128 B of path state per ray.
+    step_ms = sum(st["render_ms"] for s in stats for st in s)
+    if step_ms > 0:
+        b_ray = compulsory = 0.0
+        for f, st_frame in zip(frames, zip(*stats)):
+            r = sum(s["rays"] for s in st_frame)
+            b_ray += r * (32.0 * f.nodes_per_ray + 32.0 * f.prims_per_ray + 128.0)
+            compulsory += r * 128.0
+        roof["survey_b_ray_frac"] = round(b_ray / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
+        roof["compulsory_128B_frac"] = round(compulsory / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
+        roof["survey_note"] = ("survey_b_ray_frac charges every node visit and primitive test as if it came from HBM; for a scene resident "
+                               "in L2 those are cache hits, so it is a cache-bandwidth figure and may exceed 1; compulsory_128B_frac is the "
+                               "part that has to touch HBM in a wavefront formulation")
     if valu:
         roof["valu"] = valu
     if bound == "valu":
@@ -376,26 +436,37 @@ def kernel_rooflines(frames, stats, steps, workload, use_committed, width=0, spp
 
 
 def other_configs(device, n_synth):
-    """One frame each of BASELINE.json's configs[0..2] at their full sizes, outside the timed steps of the default
-    workload: ms per frame (second of two renders), Mrays/s, the kernel that took the most time and its HBM figures."""
+    """One step each of BASELINE.json's five configs at their full sizes, outside the timed steps of the default
+    workload: ms per frame, Mrays/s, the kernel that took the most time and its HBM figures.  A config is warmed up with
+    one full render when that is cheap (under 2^31 paths) and with a one-sample render of the same frames otherwise
+    (allocations, kernel loading); the frames of a config are rendered one after the other (a context holds up to 78 GB
+    of path queues; the two of the largest config fit side by side)."""
     rows = []
     for wl in OTHER_CONFIGS:
         frames_cfg, width, aspect, spp = WORKLOADS[wl]
-        frames = [Frame(n, width, aspect, spp, 0, 1, device, n_synth) for n in frames_cfg]
-        for f in frames:
+        frames, st, dt, build_s = [], [], 0.0, 0.0
+        for n in frames_cfg:
+            t0 = time.perf_counter()
+            f = Frame(n, width, aspect, spp, 0, 1, device, n_synth)
+            build_s += time.perf_counter() - t0
             f.ctx.profile(events=True)
-            f.render(exchange=False)  # allocations, kernel loading
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        st = [f.render(exchange=False) for f in frames]
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        roof = kernel_rooflines(frames, [st], 1, wl, use_committed=False)
+            n_paths = f.w * f.h * spp
+            f.ctx.reserve(n_paths)
+            f.render(spp=spp if n_paths <= (1 << 31) else 1, exchange=False)  # allocations, kernel loading
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st.append(f.render(exchange=False))
+            torch.cuda.synchronize()
+            dt += time.perf_counter() - t0
+            frames.append(f)
+        roof = kernel_rooflines(frames, [st], 1, wl, use_committed=True)
         rays = sum(s["rays"] for s in st)
         rows.append({"workload": wl, "frames": list(frames_cfg), "width": width, "height": frames[0].h, "spp": spp,
                      "ms_per_frame": round(dt * 1e3 / len(frames), 3), "ms_per_step": round(dt * 1e3, 3),
-                     "mrays_per_s": round(rays / dt / 1e6, 1), "rays_per_step": rays,
+                     "mrays_per_s": round(rays / dt / 1e6, 1), "rays_per_step": rays, "scene_build_s": round(build_s, 2),
                      "dominant_kernel": roof["kernel"], "bound": roof["bound"], "hbm_frac": roof["frac"],
+                     "hbm_bytes_source": roof["bytes_source"], "traffic_source": roof["traffic_source"],
+                     "survey_b_ray_frac": roof.get("survey_b_ray_frac"), "compulsory_128B_frac": roof.get("compulsory_128B_frac"),
                      "kernel_ms": {k[:-12]: roof[k] for k in roof if k.endswith("_ms_per_step") and roof[k] > 0}})
         for f in frames:
             f.ctx.close()

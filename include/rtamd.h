@@ -258,6 +258,7 @@ typedef struct rt_render_stats {
     uint64_t settled_rays; /* rays whose hit in the first medium was found by the bounce before them, without the tree walk (included in rays) */
     double settled_ms;     /* HIP-event time of the kernel that follows those paths in registers (profile flag 1) */
     uint64_t settled_launches;
+    uint64_t settled_entries; /* path-queue entries that kernel read (all it moves through memory besides the paths that leave it) */
 } rt_render_stats;
 
 int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_render_params* params, float* accum_rgb,

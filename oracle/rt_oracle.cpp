@@ -260,6 +260,14 @@ struct PathCtx {
 thread_local PathCtx* g_path = nullptr;
 thread_local bool g_media_deferred = false;  // see world_intersect
 thread_local uint64_t g_cnt_rays = 0, g_cnt_box = 0, g_cnt_prim = 0;
+// RT_ORACLE_FAST (the build bench.py times as the CPU baseline, oracle/Makefile): the box-test and primitive-test
+// counters are compiled out -- the reference has none -- while the ray counter, one increment per world.intersect call,
+// stays (it is the numerator of Mrays/s).  Results are the same bit for bit (tests/test_cpu_suite.py).
+#ifdef RT_ORACLE_FAST
+#define ORC_COUNT(c) ((void)0)
+#else
+#define ORC_COUNT(c) ((c)++)
+#endif
 
 // src/vec3_helpers.rs:7-60
 inline bool is_near_zero(V3 v) {
@@ -313,7 +321,7 @@ struct Ray {
 struct AABB {
     V3 min{INF, INF, INF}, max{-INF, -INF, -INF};
     bool hit(const Ray& ray, float /*t_min*/, float /*t_max*/) const {
-        g_cnt_box++;
+        ORC_COUNT(g_cnt_box);
         V3 recip{1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z};
         V3 mn = (min - ray.origin) * recip;
         V3 mx = (max - ray.origin) * recip;
@@ -558,7 +566,7 @@ struct Sphere : Hittable {  // src/shapes.rs:99-165
     int id = -1;
     Sphere(V3 c, float r, MPtr m) : center(c), radius(r), material(std::move(m)) {}
     bool intersect(const Ray& ray, float t_min, float t_max, HitRecord& rec) const override {
-        g_cnt_prim++;
+        ORC_COUNT(g_cnt_prim);
         V3 oc = ray.origin - center;
         float a = length_squared(ray.direction);
         float half_b = dot(oc, ray.direction);
@@ -602,7 +610,7 @@ struct MovingSphere : Hittable {  // src/shapes.rs:167-250
         : c0(a), c1(b), radius(r), t_start(ts), t_end(te), material(std::move(m)) {}
     V3 center(float time) const { return c0 + (((time - t_start) / (t_end - t_start)) * (c1 - c0)); }
     bool intersect(const Ray& ray, float t_min, float t_max, HitRecord& rec) const override {
-        g_cnt_prim++;
+        ORC_COUNT(g_cnt_prim);
         V3 oc = ray.origin - center(ray.time);
         float a = length_squared(ray.direction);
         float half_b = dot(oc, ray.direction);
@@ -651,7 +659,7 @@ struct Rect : Hittable {
     Rect(float mn0, float mn1, float mx0, float mx1, float off, MPtr m)
         : min0(mn0), min1(mn1), max0(mx0), max1(mx1), offset(off), material(std::move(m)) {}
     bool intersect(const Ray& ray, float t_min, float t_max, HitRecord& rec) const override {
-        g_cnt_prim++;
+        ORC_COUNT(g_cnt_prim);
         constexpr int A0 = (AXIS == 0) ? 1 : 0;
         constexpr int A1 = (AXIS == 2) ? 1 : 2;
         float t = (offset - axis_of(ray.origin, AXIS)) / axis_of(ray.direction, AXIS);

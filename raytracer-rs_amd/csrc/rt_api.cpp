@@ -1779,6 +1779,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_render_params* p, float*
     if (n_owned && n_samples_total) {
         st.tail_rays = c->h_rays[8];
         st.settled_rays = c->h_rays[16];
+        st.settled_entries = c->h_rays[30];
         if (c->print_hist) { fprintf(stderr, "[rtamd] hist:"); for (int k = 17; k < 32; k++) fprintf(stderr, " %llu", c->h_rays[k]); fprintf(stderr, "\n"); }
         st.rays = c->h_rays[0] + st.tail_rays;
         st.node_visits = c->h_rays[1];

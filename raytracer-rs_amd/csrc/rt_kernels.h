@@ -91,7 +91,8 @@ struct TraceCfg {
 
 // stats: 64-bit words: [0] += rays traced by the per-bounce kernels; with count_visits also [1] += inner nodes
 // fetched, [2] += primitive records tested ([3..7]: section cycles of the instrumented fused kernel);
-// [8] += rays traced by the tail kernel; [16] += rays k_settled followed without the tree walk (also in [0]).
+// [8] += rays traced by the tail kernel; [16] += rays k_settled followed without the tree walk (also in [0]);
+// [30] += queue entries k_settled took up (a path it hands on to the next launch is taken up again there).
 
 // ---- split pipeline: raygen, then per bounce trace + shade --------------------------------------------
 hipError_t launch_raygen(hipStream_t s, const Tuning& tn, const RenderConst& rc, const Batch& batch, PathState out, Queues q);

@@ -755,7 +755,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETT
     p.o = p.d = p.T = mk3(0.0f, 0.0f, 0.0f);
     p.time = 0.0f;
     p.k0 = p.k1 = p.slot = 0u;
-    uint32_t rays = 0;
+    uint32_t rays = 0, taken = 0;
     const uint32_t drain = bounce + 1u >= rc.max_depth ? 1u : DRAIN;
 #ifdef RT_SECTIONS  // wave cycles per section of the loop (s_memtime), summed into stats[24..28]; [29] counts loop rounds
     unsigned long long cyc[5] = {0, 0, 0, 0, 0}, rounds = 0, t0 = 0, t1 = 0;
@@ -808,6 +808,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETT
                     load_path(in, at, p);
                     p.settled = in.settled[at];
                     have = true;
+                    taken++;
                 }
             }
             RT_SECTION(0, "v"(p.o.x), "v"(p.d.x), "v"(p.T.x), "v"(p.k0), "v"(p.settled));
@@ -934,10 +935,14 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETT
         atomicAdd(stats + 29, rounds);
     }
 #endif
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_down(rays, off, 64);
+        taken += __shfl_down(taken, off, 64);
+    }
     if (lane == 0u && rays) {
         atomicAdd(stats, (unsigned long long)rays);
         atomicAdd(stats + 16, (unsigned long long)rays);
+        atomicAdd(stats + 30, (unsigned long long)taken);
     }
 }
 

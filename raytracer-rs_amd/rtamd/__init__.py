@@ -67,7 +67,7 @@ class rt_render_stats(C.Structure):
                 ("bounce_ms", C.c_double), ("bounce_kernel_launches", C.c_uint64), ("pipeline", C.c_uint32),
                 ("tail_launches", C.c_uint32), ("tail_rays", C.c_uint64), ("tail_ms", C.c_double),
                 ("paths_ms", C.c_double), ("paths_launches", C.c_uint64), ("settled_rays", C.c_uint64),
-                ("settled_ms", C.c_double), ("settled_launches", C.c_uint64)]
+                ("settled_ms", C.c_double), ("settled_launches", C.c_uint64), ("settled_entries", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

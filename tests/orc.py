@@ -20,16 +20,23 @@ c_u32p = C.POINTER(C.c_uint32)
 c_u64p = C.POINTER(C.c_uint64)
 c_i64p = C.POINTER(C.c_int64)
 
+_FAST_PATH = ROOT / "oracle" / "liboracle_fast.so"  # -O3 build without the visit counters: the timed CPU baseline
+
 _lib = None
+_libs = {}
 
 
-def lib():
+def lib(path=None):
+    """The checker build (default), or the oracle built at `path` (the fast build / one built for this host)."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    if not _LIB_PATH.exists():
-        raise RuntimeError(f"{_LIB_PATH} missing: run `make -C oracle` (or __graft_entry__.build())")
-    L = C.CDLL(str(_LIB_PATH))
+    path = Path(path) if path is not None else _LIB_PATH
+    if str(path) in _libs:
+        return _libs[str(path)]
+    if not path.exists():
+        raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
+    L = C.CDLL(str(path))
     L.orc_scene_create.restype = C.c_void_p
     L.orc_scene_create.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int64]
     L.orc_scene_destroy.argtypes = [C.c_void_p]
@@ -75,7 +82,9 @@ def lib():
     L.orc_kat_scatter.argtypes = [C.c_int, c_fp, c_f, c_fp, c_fp, c_fp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint32, c_fp]
     L.orc_kat_camera_ray.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, c_fp]
-    _lib = L
+    _libs[str(path)] = L
+    if path == _LIB_PATH:
+        _lib = L
     return L
 
 
@@ -123,8 +132,8 @@ DEFAULT_THREADS = min(16, os.cpu_count() or 1)
 
 
 class Scene:
-    def __init__(self, name, seed=1, n_synth=0):
-        L = lib()
+    def __init__(self, name, seed=1, n_synth=0, lib_path=None):
+        L = self._L = lib(lib_path)
         img = earthmap() if name in ("earth", "final_scene") else None
         ih, iw = (img.shape[0], img.shape[1]) if img is not None else (0, 0)
         self._img = img
@@ -145,7 +154,7 @@ class Scene:
 
     def close(self):
         if self.h:
-            lib().orc_scene_destroy(self.h)
+            self._L.orc_scene_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -157,13 +166,13 @@ class Scene:
     def spheres(self):
         """(n_top, 4) array cx,cy,cz,r of the top-level plain spheres (NaN rows for other objects)."""
         out = np.empty((self.n_top, 4), dtype=np.float32)
-        lib().orc_scene_spheres(self.h, self.n_top, _ptr(out))
+        self._L.orc_scene_spheres(self.h, self.n_top, _ptr(out))
         return out
 
     def gen_rays(self, w, h, aspect, seed=1, which=0):
         rays = np.zeros((7, w * h), dtype=np.float32)
         valid = np.zeros(w * h, dtype=np.uint8)
-        rc = lib().orc_gen_rays(self.h, w, h, aspect, seed, which, _ptr(rays), _ptr(valid))
+        rc = self._L.orc_gen_rays(self.h, w, h, aspect, seed, which, _ptr(rays), _ptr(valid))
         assert rc == 0
         return rays, valid.astype(bool)
 
@@ -175,7 +184,7 @@ class Scene:
             normal=np.empty((n, 3), np.float32), front=np.empty(n, np.uint8), uv=np.empty((n, 2), np.float32),
             point=np.empty((n, 3), np.float32))
         counters = np.zeros(3, np.uint64)
-        rc = lib().orc_intersect_batch(
+        rc = self._L.orc_intersect_batch(
             self.h, mode, n, *[_ptr(rays[i]) for i in range(7)], tmin, tmax, seed,
             _ptr(out["prim"]), _ptr(out["inst"]), _ptr(out["t"]), _ptr(out["normal"]), _ptr(out["front"]),
             _ptr(out["uv"]), _ptr(out["point"]), _ptr(counters), threads)
@@ -192,7 +201,7 @@ class Scene:
         x0, y0, x1, y1 = tile if tile is not None else (0, 0, w, h)
         rays = C.c_uint64(0)
         counters = np.zeros(3, np.uint64)
-        rc = lib().orc_render(self.h, mode, w, h, aspect, s0, s0 + spp, depth, seed, x0, y0, x1, y1,
+        rc = self._L.orc_render(self.h, mode, w, h, aspect, s0, s0 + spp, depth, seed, x0, y0, x1, y1,
                               _ptr(sum_rgb), C.byref(rays), _ptr(counters), threads)
         assert rc == 0
         if want_counters:

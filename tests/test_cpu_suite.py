@@ -63,6 +63,26 @@ def test_oracle_render_is_partition_and_sample_split_invariant():
     assert np.array_equal(split, full)
 
 
+@pytest.mark.parametrize("name", ["final_scene", "random_world", "cornell_smoke"])
+def test_fast_oracle_build_gives_the_checker_builds_bits(name):
+    """bench.py times the oracle built with -O3 and without the visit counters (oracle/Makefile: liboracle_fast.so) as
+    the CPU baseline; the tests check against the -O2 build.  Both are -ffp-contract=off, so images, ray counts and hit
+    records must be identical -- otherwise the timed program would not be the checked one."""
+    w, h, spp = 96, 96, 3
+    a = orc.Scene(name, seed=1)
+    b = orc.Scene(name, seed=1, lib_path=orc._FAST_PATH)
+    for mode in (0, 1):
+        img_a, rays_a = a.render(w, h, 1.0, spp, depth=50, seed=3, mode=mode)
+        img_b, rays_b = b.render(w, h, 1.0, spp, depth=50, seed=3, mode=mode)
+        assert rays_a == rays_b and np.array_equal(img_a, img_b)
+    rays, valid = a.gen_rays(64, 64, 1.0, seed=2, which=1)
+    ha, hb = a.intersect(rays, seed=2), b.intersect(rays, seed=2)
+    for k in ("prim", "inst", "t", "normal", "front", "uv", "point"):
+        assert np.array_equal(ha[k][valid], hb[k][valid], equal_nan=True), k
+    a.close()
+    b.close()
+
+
 def test_earthmap_fixture():
     import hashlib
     img = orc.earthmap()
