@@ -197,19 +197,20 @@ typedef struct rt_camera {
  * -(k+2) for the k-th medium group), inst (index of the instance group hit, else -1), t,
  * normal (n x 3, face-set as hit_record.rs:32-42), front, uv (n x 2), point (n x 3).
  * Media take their free-flight sample from RNG stream (seed, pixel = ray index, sample 0), bounce 0.
- * All pointers: host or device (all of one kind). */
+ * All pointers: host or device, all of one kind (a mix is RT_ERR_INVALID). */
 int rt_intersect_batch(rt_ctx* ctx, uint64_t n, const float* ox, const float* oy, const float* oz,
                        const float* dx, const float* dy, const float* dz, const float* time, float tmin,
                        float tmax, uint32_t seed, int32_t* prim, int32_t* inst, float* t, float* normal,
                        uint8_t* front, float* uv, float* point);
 
-/* The same call for callers that must not allocate (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc).  It has no counterpart in the reference.  rt_intersect_batch allocates: its overflow flag
- * on first use, and staging buffers on every call that passes host arrays.  This variant keeps both in a static
- * device array of 5 MiB (256 bytes of flags + 76 bytes of staging per ray) that each GPU the library runs on holds
- * until the process ends, and calls no hipMalloc / hipFree.  Limit: n <= 65536 rays per call (RT_ERR_INVALID beyond
- * it); same arguments, same results bit for bit.  Every call on a GPU shares that GPU's array: calls that overlap on
- * one GPU (two contexts on two host threads) race -- serialise them. */
+/* The same call for callers that must not allocate (tight serving loops, harnesses that forbid hipMalloc, processes
+ * whose device memory is spoken for).  It has no counterpart in the reference.  rt_intersect_batch allocates: its
+ * overflow flag on first use, and staging buffers on every call that passes host arrays.  This variant keeps both in a
+ * static device array of 5 MiB (256 bytes of flags + 76 bytes of staging per ray) that each GPU the library runs on
+ * holds until the process ends, and calls no hipMalloc / hipFree.  Like rt_intersect_batch it waits for its stream
+ * and reads the overflow flag back before it returns, so it cannot be recorded into a HIP graph.  Limit: n <= 65536
+ * rays per call (RT_ERR_INVALID beyond it); same arguments, same results bit for bit.  Every call on a GPU shares that
+ * GPU's array: calls that overlap on one GPU (two contexts on two host threads) race -- serialise them. */
 #define RT_NOALLOC_MAX_RAYS 65536u
 int rt_intersect_batch_noalloc(rt_ctx* ctx, uint64_t n, const float* ox, const float* oy, const float* oz,
                                const float* dx, const float* dy, const float* dz, const float* time, float tmin,

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1223,6 +1224,19 @@ int rt_scene_read_bvh(rt_ctx* c, void* nodes, uint64_t nodes_bytes, void* prims,
     return RT_OK;
 }
 
+namespace {
+// true when the non-null pointers among the 14 are all device memory or all host memory; *dev says which
+bool one_kind(const void* const in[7], const void* const out[7], bool* dev) {
+    int n_dev = 0, n_host = 0;
+    for (int k = 0; k < 7; k++) {
+        if (in[k]) (is_device_ptr(in[k]) ? n_dev : n_host)++;
+        if (out[k]) (is_device_ptr(out[k]) ? n_dev : n_host)++;
+    }
+    *dev = n_dev > 0;
+    return n_dev == 0 || n_host == 0;
+}
+}  // namespace
+
 int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, const float* oz, const float* dx,
                        const float* dy, const float* dz, const float* time, float tmin, float tmax, uint32_t seed,
                        int32_t* prim, int32_t* inst, float* t, float* normal, uint8_t* front, float* uv, float* point) {
@@ -1233,7 +1247,10 @@ int rt_intersect_batch(rt_ctx* c, uint64_t n, const float* ox, const float* oy, 
     if (n > (1ull << 32)) return fail(c, RT_ERR_INVALID, "rt_intersect_batch: more than 2^32 rays");
     HIP_TRY(c, hipSetDevice(c->device));
     const float* in[7] = {ox, oy, oz, dx, dy, dz, time};
-    const bool dev = is_device_ptr(ox);
+    const void* const all_in[7] = {ox, oy, oz, dx, dy, dz, time};
+    const void* const all_out[7] = {prim, inst, t, normal, front, uv, point};
+    bool dev = false;
+    if (!one_kind(all_in, all_out, &dev)) return fail(c, RT_ERR_INVALID, "rt_intersect_batch: host and device pointers mixed in one call");
     int rc;
     if ((rc = ensure(c, c->d_overflow, 16))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_overflow.p, 0, 4, c->stream));
@@ -1307,8 +1324,12 @@ int rt_intersect_batch_noalloc(rt_ctx* c, uint64_t n, const float* ox, const flo
     uint32_t* const flag = (uint32_t*)sc;
     const float* in[7] = {ox, oy, oz, dx, dy, dz, time};
     const rtk::TraceCfg cfg{c->stack_entries, c->has_groups, false, c->scene.nested != 0u};
+    const void* const all_in[7] = {ox, oy, oz, dx, dy, dz, time};
+    const void* const all_out[7] = {prim, inst, t, normal, front, uv, point};
+    bool dev = false;
+    if (!one_kind(all_in, all_out, &dev)) return fail(c, RT_ERR_INVALID, "rt_intersect_batch_noalloc: host and device pointers mixed in one call");
     HIP_TRY(c, hipMemsetAsync(flag, 0, 4, c->stream));  // the array keeps the last call's contents
-    if (is_device_ptr(ox)) {
+    if (dev) {
         HIP_TRY(c, rtk::launch_intersect_batch(c->stream, cfg, c->scene, n, in, tmin, tmax, seed, prim, inst, t, normal, front, uv, point, flag));
     } else {
         // host arrays: staged through the scratch
@@ -1373,7 +1394,9 @@ struct UniqueId {
     char internal[128];  // ncclUniqueId: NCCL_UNIQUE_ID_BYTES, passed by value
 };
 struct Rccl {
-    bool tried = false, ok = false;
+    std::once_flag once;
+    bool ok = false;
+    bool from_process = false;  // the symbols are those of an RCCL the process had loaded already
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
@@ -1381,20 +1404,28 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
+// Resolved once per process (call_once: contexts may be driven from several host threads).  An RCCL the process already
+// holds wins -- whatever its soname or path, or linked statically: a communicator the host made (rt_comm_attach) must be
+// driven by the library that made it -- and only when the process has none is librccl.so opened from the loader path.
+// (RTLD_DEFAULT is a null handle on glibc, so "found in the process" is tracked apart from the dlopen handle.)
 bool rccl_load() {
-    if (g_rccl.tried) return g_rccl.ok;
-    g_rccl.tried = true;
-    void* h = nullptr;
-    if (dlsym(RTLD_DEFAULT, "ncclAllGather")) h = RTLD_DEFAULT;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
-    for (int k = 0; !h && k < 3; k++) h = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return false;
-    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (int (*)(void**, int, UniqueId, int))dlsym(h, "ncclCommInitRank");
-    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
-    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
-    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather;
+    std::call_once(g_rccl.once, [] {
+        Rccl& r = g_rccl;
+        r.from_process = dlsym(RTLD_DEFAULT, "ncclAllGather") != nullptr;
+        void* h = nullptr;
+        if (!r.from_process) {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+            for (int k = 0; !h && k < 3; k++) h = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
+            if (!h) return;
+        }
+        auto sym = [&](const char* name) { return dlsym(r.from_process ? RTLD_DEFAULT : h, name); };
+        r.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
+        r.CommInitRank = (int (*)(void**, int, UniqueId, int))sym("ncclCommInitRank");
+        r.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))sym("ncclAllGather");
+        r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+    });
     return g_rccl.ok;
 }
 int rccl_fail(rt_ctx* c, int code, const char* what) {

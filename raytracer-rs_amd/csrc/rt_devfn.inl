@@ -556,6 +556,15 @@ DEV void walk_set_ray(Walk& w, f3 o, f3 d) {
     w.oi_n = oi - e;
     w.oi_f = oi + e;
 }
+// A ray with a NaN or infinite component (one path in ~10^8 produces one) has no defined closest hit: every comparison of
+// the reference's tests is false for it, so each primitive "hits" and the last one visited wins -- whichever that is in the
+// reference's random tree.  Here such a ray hits NOTHING, in every way of tracing alike: the tree is not walked (with all
+// box tests passing it would visit every node, bounce after bounce), the loop over a flat scene is not run, and the
+// media are not asked.
+DEV bool ray_is_finite(f3 wo, f3 wd) {
+    const float chk = ((wo.x + wo.y) + wo.z) + ((wd.x + wd.y) + wd.z);
+    return __builtin_fabsf(chk) < INF_F;
+}
 DEV void walk_begin(const Scene& S, Walk& w, f3 wo, f3 wd, float tmax) {
     w.best.t = tmax;
     w.best.prim = HIT_NONE;
@@ -565,12 +574,7 @@ DEV void walk_begin(const Scene& S, Walk& w, f3 wo, f3 wd, float tmax) {
     walk_set_ray(w, wo, wd);
     w.grp = -1;
     w.sp = 0;
-    // A ray with a NaN or infinite component (one path in ~10^8 produces one) has no defined closest hit: every
-    // comparison of the reference's tests is false for it, so each primitive "hits" and the last one visited
-    // wins -- whichever that is in the reference's random tree.  Here such a ray misses the tree: nothing is
-    // walked (with all box tests passing it would visit every node, bounce after bounce).
-    const float chk = ((wo.x + wo.y) + wo.z) + ((wd.x + wd.y) + wd.z);
-    if (!(__builtin_fabsf(chk) < INF_F)) w.cur = REF_EMPTY;
+    if (!ray_is_finite(wo, wd)) w.cur = REF_EMPTY;  // (see ray_is_finite)
 }
 // Conservative slab test of the walk: entry distance in tn; false only when the box certainly holds no hit in
 // [tmin, tbest].  The near plane of each axis is picked by the sign of inv (one select instead of a min and a max).
@@ -755,6 +759,7 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
 template <bool COUNT, bool NESTED>
 DEV void apply_media(const Scene& S, f3 wo, f3 wd, float time, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce, Hit& best,
                      TraceCount* cnt) {
+    if (!ray_is_finite(wo, wd)) return;  // (see ray_is_finite)
     for (uint32_t m = 0; m < S.n_media; m++) {
         test_medium<NESTED>(S, S.media[m], wo, wd, time, tmin, k0, k1, bounce, best);
         if (COUNT) cnt->prims += 2u * medium_boundary_count(S.groups[S.media[m]]);  // two boundary queries
@@ -771,6 +776,7 @@ DEV void trace_flat(const Scene& S, f3 wo, f3 wd, float time, float tmin, float 
     best.prim = HIT_NONE;
     best.grp = -1;
     best.key = 0;
+    if (!ray_is_finite(wo, wd)) return;  // (hits nothing, as in the tree walk)
     const float a = dot3(wd, wd);
     for (uint32_t i = 0; i < S.world_count; i++) test_prim<true>(S, S.world_first + i, wo, wd, a, time, tmin, -1, best);
     if (COUNT) cnt->prims += S.world_count;

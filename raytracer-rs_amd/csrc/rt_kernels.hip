@@ -450,8 +450,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
                 have = true;
                 if (COUNT) {
                     tc.prims += media_prims;
-                    const float chk = ((wo.x + wo.y) + wo.z) + ((wd.x + wd.y) + wd.z);
-                    if (!(__builtin_fabsf(chk) < INF_F)) atomicAdd(stats + 15, 1ull);  // rays with a NaN or infinite component
+                    if (!ray_is_finite(wo, wd)) atomicAdd(stats + 15, 1ull);  // rays with a NaN or infinite component
                 }
             }
         }
@@ -594,8 +593,9 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             h.prim = __float_as_uint(hv.y);
             h.grp = __float_as_int(hv.z);
             h.key = __float_as_uint(hv.w);
-            for (uint32_t m = 0; m < S.n_media; m++)
-                test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, p.bounce, h);
+            if (ray_is_finite(p.o, p.d))  // (as apply_media)
+                for (uint32_t m = 0; m < S.n_media; m++)
+                    test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, p.bounce, h);
 #ifdef RT_HIST
             if (p.bounce >= 16u) {
                 uint32_t cls = 4u;
