@@ -30,6 +30,8 @@ pub const RT_TRANSFER_LINEAR: c_int = 0;
 pub const RT_TRANSFER_SQRT: c_int = 1;
 pub const RT_IMAGE_PNG: c_int = 0;
 pub const RT_IMAGE_PPM: c_int = 1;
+pub const RT_NOALLOC_MAX_RAYS: u32 = 65536;
+pub const RT_DEFAULT_TILE: u32 = 16;
 
 #[repr(C)]
 #[derive(Default, Clone, Copy)]
@@ -132,6 +134,9 @@ pub struct rt_render_stats {
     pub paths_ms: f64,
     pub paths_launches: u64,
     pub settled_rays: u64,
+    pub settled_ms: f64,
+    pub settled_launches: u64,
+    pub settled_entries: u64,
 }
 
 extern "C" {
@@ -146,6 +151,7 @@ extern "C" {
     pub fn rt_ctx_set_tail_paths(ctx: *mut rt_ctx, tail_paths: u64) -> c_int;
     pub fn rt_ctx_set_builder(ctx: *mut rt_ctx, builder: c_int) -> c_int;
     pub fn rt_ctx_set_bvh_width(ctx: *mut rt_ctx, width: c_int) -> c_int;
+    pub fn rt_ctx_set_fuse_boxes(ctx: *mut rt_ctx, on: c_int) -> c_int;
     pub fn rt_scene_clear(ctx: *mut rt_ctx) -> c_int;
     pub fn rt_scene_set_spheres(ctx: *mut rt_ctx, n: u32, c0_r: *const f32, c1: *const f32, t01: *const f32,
                                 moving: *const u8, mat: *const u32, id: *const u32, group: *const u32) -> c_int;
@@ -164,6 +170,10 @@ extern "C" {
                               dy: *const f32, dz: *const f32, time: *const f32, tmin: f32, tmax: f32, seed: u32,
                               prim: *mut i32, inst: *mut i32, t: *mut f32, normal: *mut f32, front: *mut u8,
                               uv: *mut f32, point: *mut f32) -> c_int;
+    pub fn rt_intersect_batch_noalloc(ctx: *mut rt_ctx, n: u64, ox: *const f32, oy: *const f32, oz: *const f32,
+                                      dx: *const f32, dy: *const f32, dz: *const f32, time: *const f32, tmin: f32,
+                                      tmax: f32, seed: u32, prim: *mut i32, inst: *mut i32, t: *mut f32, normal: *mut f32,
+                                      front: *mut u8, uv: *mut f32, point: *mut f32) -> c_int;
     pub fn rt_render(ctx: *mut rt_ctx, cam: *const rt_camera, params: *const rt_render_params, accum_rgb: *mut f32,
                      stats: *mut rt_render_stats) -> c_int;
     pub fn rt_profile_enable(ctx: *mut rt_ctx, flags: c_int) -> c_int;
@@ -175,6 +185,22 @@ extern "C" {
                           accum_rgb: *const f32) -> c_int;
     pub fn rt_accum_read(path: *const c_char, width: *mut u32, height: *mut u32, samples_done: *mut u32, seed: *mut u32,
                          accum_rgb: *mut f32, cap_floats: u64) -> c_int;
+    pub fn rt_accum_write_tagged(path: *const c_char, width: u32, height: u32, samples_done: u32, seed: u32, tag: u64,
+                                 accum_rgb: *const f32) -> c_int;
+    pub fn rt_accum_read_tagged(path: *const c_char, width: *mut u32, height: *mut u32, samples_done: *mut u32,
+                                seed: *mut u32, tag: *mut u64, accum_rgb: *mut f32, cap_floats: u64) -> c_int;
     pub fn rt_owned_pixels(width: u32, height: u32, tile_size: u32, rank: u32, nranks: u32, out: *mut u32, cap: u64,
                            n: *mut u64) -> c_int;
+    // frame exchange between ranks (one RCCL all-gather per frame behind rt_gather_frame)
+    pub fn rt_comm_unique_id(out: *mut u8) -> c_int;
+    pub fn rt_comm_create(ctx: *mut rt_ctx, unique_id: *const u8, rank: u32, nranks: u32) -> c_int;
+    pub fn rt_comm_attach(ctx: *mut rt_ctx, nccl_comm: *mut c_void, rank: u32, nranks: u32) -> c_int;
+    pub fn rt_comm_destroy(ctx: *mut rt_ctx) -> c_int;
+    pub fn rt_gather_frame(ctx: *mut rt_ctx, width: u32, height: u32, tile_size: u32, accum_rgb: *const f32,
+                           frame_rgb: *mut f32) -> c_int;
+    pub fn rt_frame_block_pixels(width: u32, height: u32, tile_size: u32, nranks: u32, out: *mut u64) -> c_int;
+    pub fn rt_pack_owned(ctx: *mut rt_ctx, width: u32, height: u32, tile_size: u32, rank: u32, nranks: u32,
+                         accum_rgb: *const f32, packed: *mut f32) -> c_int;
+    pub fn rt_scatter_gathered(ctx: *mut rt_ctx, width: u32, height: u32, tile_size: u32, nranks: u32,
+                               gathered: *const f32, frame_rgb: *mut f32) -> c_int;
 }

@@ -106,6 +106,79 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"librtamd.so does not export {n}"
 
 
+def _header_text():
+    text = (ROOT / "include" / "rtamd.h").read_text()
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def _c_kind(ctype):
+    """A C parameter or field type reduced to what its Rust counterpart must be."""
+    t = " ".join(ctype.replace("const", " ").split())
+    ptr = t.count("*")
+    base = t.replace("*", "").strip()
+    scalar = {"int": "i32", "uint8_t": "u8", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "double": "f64",
+              "char": "c_char", "void": "c_void", "size_t": "usize"}.get(base, base)
+    return ("*" * ptr) + scalar
+
+
+def _rust_kind(rtype):
+    t = rtype.replace("*const", "*").replace("*mut", "*").replace(" ", "")
+    return t.replace("c_int", "i32")
+
+
+def test_rust_declarations_match_the_header():
+    """bindings/rust/src/ffi.rs cannot be compiled here (no Rust toolchain), so it is checked as text against
+    include/rtamd.h: the same functions, each with the same number of parameters of the same kinds in the same order,
+    and the same struct fields in the same order with the same element types and array lengths."""
+    header = _header_text()
+    rust = re.sub(r"//[^\n]*", "", (ROOT / "bindings" / "rust" / "src" / "ffi.rs").read_text())
+    # ---- functions
+    c_funcs = {}
+    for ret, name, params in re.findall(r"\b(int|void|const char\s*\*)\s+(rt_\w+)\s*\(([^;{]*?)\)\s*;", header):
+        kinds = []
+        for prm in (x.strip() for x in params.split(",")):
+            if prm in ("", "void"):
+                continue
+            m = re.match(r"(.*?)(\w+)\s*(\[\d*\])?$", prm)
+            kinds.append(_c_kind(m.group(1) + ("*" if m.group(3) else "")))
+        c_funcs[name] = kinds
+    r_funcs = {}
+    for name, params in re.findall(r"pub fn (rt_\w+)\s*\(([^)]*)\)", rust):
+        r_funcs[name] = [_rust_kind(x.split(":", 1)[1]) for x in params.split(",") if ":" in x]
+    assert sorted(c_funcs) == declared_functions()
+    assert sorted(r_funcs) == sorted(c_funcs), f"only in the header: {sorted(set(c_funcs) - set(r_funcs))}; only in ffi.rs: {sorted(set(r_funcs) - set(c_funcs))}"
+    for name, kinds in c_funcs.items():
+        assert r_funcs[name] == kinds, f"{name}: header {kinds} against ffi.rs {r_funcs[name]}"
+    # ---- structs
+    c_structs = {}
+    for body, name in re.findall(r"typedef struct \w+\s*\{(.*?)\}\s*(rt_\w+)\s*;", header, flags=re.S):
+        fields = []
+        for decl in (d.strip() for d in body.split(";")):
+            if not decl:
+                continue
+            ctype, rest = decl.split(None, 1)
+            for item in rest.split(","):
+                m = re.match(r"\s*(\w+)\s*(?:\[(\d+)\])?\s*$", item)
+                fields.append((m.group(1), _c_kind(ctype), int(m.group(2) or 0)))
+        c_structs[name] = fields
+    r_structs = {}
+    for name, body in re.findall(r"pub struct (rt_\w+)\s*\{(.*?)\}", rust, flags=re.S):
+        fields = []
+        for fname, ftype in re.findall(r"pub (\w+)\s*:\s*([^,\n]+)", body):
+            m = re.match(r"\[(\w+);\s*(\d+)\]", ftype.strip())
+            fields.append((fname, m.group(1), int(m.group(2))) if m else (fname, ftype.strip(), 0))
+        r_structs[name] = fields
+    assert set(c_structs) >= {"rt_material", "rt_texture", "rt_group", "rt_scene_info", "rt_camera", "rt_render_params", "rt_render_stats"}
+    for name, fields in c_structs.items():
+        assert r_structs.get(name) == fields, f"{name}: header {fields} against ffi.rs {r_structs.get(name)}"
+    # ---- constants the two sides must agree on
+    for cname in ("RT_NOALLOC_MAX_RAYS", "RT_DEFAULT_TILE"):
+        c_val = int(re.search(rf"#define {cname} (\d+)u", header).group(1))
+        assert int(re.search(rf"pub const {cname}: u32 = (\d+);", rust).group(1)) == c_val
+    for cname, val in re.findall(r"\b(RT_(?:ERR_\w+|OK))\s*=\s*(-?\d+)", header):
+        assert re.search(rf"pub const {cname}: c_int = {val};", rust), cname
+
+
 def test_struct_layouts_match_header(tmp_path):
     """The header compiles as plain C and the ctypes mirrors have the sizes the C compiler gives."""
     names = ["rt_camera", "rt_material", "rt_texture", "rt_group", "rt_render_params", "rt_render_stats", "rt_scene_info"]
