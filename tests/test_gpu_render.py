@@ -665,14 +665,14 @@ def test_c5_like_deep_bvh_properties(gpu_ctx):
 
 
 def test_c5_ten_million_spheres_properties():
-    """BASELINE configs[4] at its full 10M spheres (1920x1080, 1 spp): the scene builds on the device, takes the
-    four-child walk and the split pipeline, a 2-rank split reproduces the 1-rank frame bit for bit, every pixel is
-    finite and inside [0, 1], and rays >= paths."""
+    """BASELINE configs[4] at its full 10M spheres and its full 3840x2160 frame (1 spp): the scene builds on the device,
+    takes the four-child walk and the split pipeline, a 2-rank split reproduces the 1-rank frame bit for bit, every
+    pixel is finite and inside [0, 1], and rays >= paths."""
     import torch
     ctx = rtamd.Context(0)
     info = ctx.load_scene("synth_spheres", seed=1, n_synth=10_000_000)
     assert info["n_prims"] == 10_000_001 and info["builder"] == 1 and info["bvh_width"] == 4 and info["stack_entries"] <= 64
-    w, h = 1920, 1080
+    w, h = 3840, 2160
     cam = ctx.preset_camera(16 / 9)
     one = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
     _, st = ctx.render(w, h, cam, 1, seed=1, accum=one)
@@ -684,6 +684,35 @@ def test_c5_ten_million_spheres_properties():
         ctx.render(w, h, cam, 1, seed=1, accum=two, rank=r, nranks=2)
     assert torch.equal(one, two)
     ctx.close()
+
+
+@pytest.mark.parametrize("name, w, aspect", [("random_world", 1920, 16 / 9), ("cornell_box", 2048, 1.0), ("cornell_smoke", 2048, 1.0)])
+def test_c3_and_c4_full_frames(name, w, aspect):
+    """BASELINE configs[2] (random world with moving spheres, 1920x1080) and configs[3] (both Cornell scenes, 2048x2048)
+    at their full frame sizes, 2 spp: the frame dealt over eight ranks equals the one-rank frame bit for bit, every pixel
+    is finite, and a 64x64 crop from the middle of the frame agrees with the oracle's render of that crop."""
+    import torch
+    h = rtamd.image_height(w, aspect)
+    spp = 2
+    ctx = rtamd.Context(0)
+    ctx.load_scene(name, seed=1)
+    cam = ctx.preset_camera(aspect)
+    one = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    _, st = ctx.render(w, h, cam, spp, seed=1, accum=one)
+    assert st["paths"] == w * h * spp and st["rays"] >= st["paths"] and bool(torch.isfinite(one).all())
+    eight = torch.zeros_like(one)
+    rays = 0
+    for r in range(8):
+        rays += ctx.render(w, h, cam, spp, seed=1, accum=eight, rank=r, nranks=8, tile_size=8)[1]["rays"]
+    assert rays == st["rays"] and torch.equal(one, eight)
+    ctx.close()
+    x0, y0 = w // 2 - 32, h // 2 - 32
+    osc = orc.Scene(name, seed=1)
+    ref, _ = osc.render(w, h, aspect, spp, depth=50, seed=1, mode=1, tile=(x0, y0, x0 + 64, y0 + 64))
+    osc.close()
+    crop = one[y0:y0 + 64, x0:x0 + 64].cpu().numpy()
+    assert crop.sum() > 0
+    assert_images_close(crop, ref[y0:y0 + 64, x0:x0 + 64], spp, f"{name} crop")
 
 
 def test_cpp_example_renders_the_same_image_as_the_python_binding(tmp_path):
