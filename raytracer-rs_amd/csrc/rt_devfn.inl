@@ -673,6 +673,18 @@ DEV void inner_step(const Scene& S, Walk& w, float tmin, const Stack& stk, uint3
     float tn0, tn1;
     bool h0 = slab_fma(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), w, tmin, w.best.t, tn0);
     bool h1 = slab_fma(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), w, tmin, w.best.t, tn1);
+#ifdef RT_INNER_TWICE  // timing experiment: both box tests a second time (same result)
+    {
+        asm volatile("" : "+v"(q0.x), "+v"(q1.z));
+        float u0, u1;
+        const bool g0 = slab_fma(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), w, tmin, w.best.t, u0);
+        const bool g1 = slab_fma(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), w, tmin, w.best.t, u1);
+        h0 = h0 && g0;
+        h1 = h1 && g1;
+        tn0 = fminf(tn0, u0);
+        tn1 = fminf(tn1, u1);
+    }
+#endif
     uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
     h0 = h0 && (c0 != REF_EMPTY);
     h1 = h1 && (c1 != REF_EMPTY);
@@ -713,6 +725,13 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
     if (type == REF_PRIMS) {
         uint32_t first = w.cur & 0x03FFFFFFu, n_leaf = ((w.cur >> 26) & 15u) + 1u;
         for (uint32_t i = 0; i < n_leaf; i++) test_prim<false>(S, first + i, w.o, w.d, w.a, time, tmin, w.grp, w.best);
+#ifdef RT_LEAF_TWICE  // timing experiment: the leaf tests a second time (same result), to price them at their present lane use
+        {
+            uint32_t f2 = first;
+            asm volatile("" : "+v"(f2), "+v"(w.best.t));
+            for (uint32_t i = 0; i < n_leaf; i++) test_prim<false>(S, f2 + i, w.o, w.d, w.a, time, tmin, w.grp, w.best);
+        }
+#endif
         if (COUNT) cnt->prims += n_leaf;
         w.cur = REF_EMPTY;
     } else if (GROUPS && type == REF_INSTANCE) {
@@ -800,12 +819,13 @@ DEV void trace_flat(const Scene& S, f3 wo, f3 wd, float time, float tmin, float 
 // are still descending do not drag the (long) primitive tests of the others along on every iteration.
 // FLAT: the scene is traced without a tree (Scene::flat); a template parameter, so that neither form carries the
 // registers of the other.
-template <int STRIDE, int GROUPS, bool FLAT, bool COUNT = false>
+// MEDIA = false: surfaces only (the caller applies the media itself).
+template <int STRIDE, int GROUPS, bool FLAT, bool COUNT = false, bool MEDIA = true>
 DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float tmax, uint32_t k0, uint32_t k1,
                    uint32_t bounce, Hit& best, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt = nullptr) {
     if (FLAT) {
         trace_flat<GROUPS != 0, COUNT>(S, wo, wd, time, tmin, tmax, best, cnt);
-        if (GROUPS) apply_media<COUNT, GROUPS == 2>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
+        if (GROUPS && MEDIA) apply_media<COUNT, GROUPS == 2>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
         return;
     }
     Walk w;
@@ -815,7 +835,7 @@ DEV void trace_ray(const Scene& S, f3 wo, f3 wd, float time, float tmin, float t
         walk_leaf<STRIDE, GROUPS, COUNT>(S, w, wo, wd, time, tmin, stk, overflow_flag, cnt);
     }
     best = w.best;
-    if (GROUPS) apply_media<COUNT, GROUPS == 2>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
+    if (GROUPS && MEDIA) apply_media<COUNT, GROUPS == 2>(S, wo, wd, time, tmin, k0, k1, bounce, best, cnt);
 }
 
 // ---- hit record (hit_record.rs, shapes.rs) --------------------------------------

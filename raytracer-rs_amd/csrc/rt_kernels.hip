@@ -272,13 +272,130 @@ DEV uint32_t primary_count(uint32_t n, uint32_t s) {
     return cnt;
 }
 
+// ---- media that are plain spheres of plain colour, from LDS (Scene::settle_fast; see k_settled) ------------------------
+struct FastMedium {
+    float cx, cy, cz, r;
+    double neg_inv_density;
+    uint32_t salt, hit, key, pad;
+    float col[3];
+    float inv_density_lo;  // a float just below 1 / density (fast_medium_misses)
+};
+struct FastLds {
+    FastMedium m[4];
+    float blo[3], bhi[3];        // widened box of the first medium's boundary (Group::blo / bhi)
+    float ncx, ncy, ncz, nr;     // the one primitive near the first medium (a resting sphere of glass), if the scene has one
+    float near_ior;
+    uint32_t same_sphere;        // that sphere equals the first medium's boundary bit for bit (final_scene: main.rs:279-282)
+};
+// The free flight of such a medium once the roots of its sphere are known (test_medium's single-sphere case).
+DEV bool fast_medium_flight(const FastMedium& M, bool line_hits, float c0, float c1, float a, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce,
+                            float best_t, float& t) {
+    float r1, r2;
+    const uint32_t have = line_hits ? 3u : 0u;
+    if (!pick_root(have, c0, c1, -INF_F, INF_F, r1)) return false;
+    if (!pick_root(have, c0, c1, r1 + 0.0001f, INF_F, r2)) return false;
+    return medium_flight(r1, r2, tmin, best_t, (double)__builtin_sqrtf(a), M.neg_inv_density, medium_xi_salted(k0, k1, bounce, M.salt), t);
+}
+// ConstantMedium::intersect for such a medium: test_medium's single-sphere case with the record in LDS.
+DEV bool fast_medium(const FastMedium& M, f3 o, f3 d, float a, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce, float best_t, float& t) {
+    float c0, c1;
+    const bool line_hits = sphere_roots(mk3(M.cx, M.cy, M.cz), M.r, o, d, a, c0, c1);
+    return fast_medium_flight(M, line_hits, c0, c1, a, tmin, k0, k1, bounce, best_t, t);
+}
+// true: fast_medium certainly returns false for a closest hit at best_t (> 0), whatever the sphere -- decided from the
+// medium's draw alone, in f32.  The medium takes a ray only if its flight -ln(xi) / density ends within the part of the ray
+// inside it, which is shorter than best_t / |d| (medium_flight: r1 >= tmin > 0, r2 <= best_t).  The hardware log2 of the
+// rounded draw is within 2e-7 relative and 6e-8 absolute of ln(xi) / ln 2; both sides carry that slack, so "misses" is never
+// said wrongly, and a draw of exactly 0 (flight +inf) misses.  For a thin medium this spares nearly every ray the f64
+// logarithm and the two f64 divisions.
+DEV bool fast_medium_misses(const FastMedium& M, float a, uint32_t k0, uint32_t k1, uint32_t bounce, float best_t) {
+    const float xi = (float)medium_xi_salted(k0, k1, bounce, M.salt);
+    const float flight_lo = M.inv_density_lo * (__builtin_amdgcn_logf(xi) * -0.69314647f - 2e-7f);  // (ln 2 rounded down a little)
+    const float inside_hi = best_t * __builtin_amdgcn_rsqf(a) * 1.000002f;
+    return flight_lo > inside_hi;
+}
+// Fills FastLds from the scene (Scene::settle_fast holds); every thread of the block must reach it.
+DEV void fill_fast_lds(const Scene& S, FastLds& fl) {
+    if (threadIdx.x < S.n_media) {
+        const uint32_t g = S.media[threadIdx.x];
+        const Group& G = S.groups[g];
+        const float4 sph = *reinterpret_cast<const float4*>(S.prims + (G.root_ref & 0x03FFFFFFu));
+        const Material& M = S.mats[G.mat];
+        FastMedium& F = fl.m[threadIdx.x];
+        F.cx = sph.x;
+        F.cy = sph.y;
+        F.cz = sph.z;
+        F.r = sph.w;
+        F.neg_inv_density = G.neg_inv_density;
+        F.salt = medium_salt(G.order);
+        F.hit = HIT_MEDIUM_BIT | g;
+        F.key = MEDIUM_KEY_BASE + G.order;
+        F.col[0] = M.albedo[0];
+        F.col[1] = M.albedo[1];
+        F.col[2] = M.albedo[2];
+        F.inv_density_lo = (float)(-G.neg_inv_density) * 0.9999995f;
+        if (threadIdx.x == 0u)
+            for (int k = 0; k < 3; k++) {
+                fl.blo[k] = G.blo[k];
+                fl.bhi[k] = G.bhi[k];
+            }
+    }
+    if (threadIdx.x == 64u) {
+        float4 sph = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float ior = 1.0f;
+        uint32_t same = 0u;
+        if (S.near0_n == 1u) {
+            const float4* rec = reinterpret_cast<const float4*>(S.prims + S.media[S.n_media]);
+            sph = rec[0];
+            ior = S.mats[__float_as_uint(rec[1].y) >> 8].ior;
+            const float4 b = *reinterpret_cast<const float4*>(S.prims + (S.groups[S.media[0]].root_ref & 0x03FFFFFFu));
+            same = (__float_as_uint(b.x) == __float_as_uint(sph.x) && __float_as_uint(b.y) == __float_as_uint(sph.y) &&
+                    __float_as_uint(b.z) == __float_as_uint(sph.z) && __float_as_uint(b.w) == __float_as_uint(sph.w)) ? 1u : 0u;
+        }
+        fl.ncx = sph.x;
+        fl.ncy = sph.y;
+        fl.ncz = sph.z;
+        fl.nr = sph.w;
+        fl.near_ior = ior;
+        fl.same_sphere = same;
+    }
+    __syncthreads();
+}
+// settle_next with the records in LDS: the same tests in the same order with the same arithmetic.
+DEV float settle_next_fast(const Scene& S, const FastLds& fl, const PathRegs& p, uint32_t near_prim) {
+    const f3 c0 = mk3(fl.m[0].cx, fl.m[0].cy, fl.m[0].cz);
+    const float rr = fl.m[0].r * 1.0005f;
+    const f3 oc = p.o - c0;
+    const bool inside = p.o.x >= fl.blo[0] && p.o.x <= fl.bhi[0] && p.o.y >= fl.blo[1] && p.o.y <= fl.bhi[1] && p.o.z >= fl.blo[2] &&
+                        p.o.z <= fl.bhi[2] && dot3(oc, oc) <= rr * rr;
+    if (!inside) return 0.0f;
+    const float a2 = dot3(p.d, p.d);
+    float q0, q1, tg = INF_F, tm;
+    const bool line_hits = sphere_roots(c0, fl.m[0].r, p.o, p.d, a2, q0, q1);
+    bool hit_g = false;
+    if (S.near0_n == 1u) {
+        // (the same sphere: its roots are the boundary's -- quotient_pair gives the quotients of sphere_candidate bit for
+        // bit -- and the root it takes is pick_root's)
+        if (fl.same_sphere) hit_g = pick_root(line_hits ? 3u : 0u, q0, q1, 0.005f, INF_F, tg);
+        else hit_g = sphere_candidate(mk3(fl.ncx, fl.ncy, fl.ncz), fl.nr, p.o, p.d, a2, 0.005f, INF_F, tg);
+    }
+    if (fast_medium_flight(fl.m[0], line_hits, q0, q1, a2, 0.005f, p.k0, p.k1, p.bounce, hit_g ? tg : INF_F, tm)) return tm > 0.0f ? tm : 0.0f;
+    if (hit_g && tg > 0.0f && near_prim != 0x7FFFFFFFu) {
+        const f3 pc = (p.o + tg * p.d) - c0;
+        if (dot3(pc, pc) <= rr * rr) return -tg;
+    }
+    return 0.0f;
+}
+
+
 // =================================================================================
 // Kernels.  Grid = NSHARD * blocks_per_shard; block b serves shard b % NSHARD.
 // =================================================================================
 
 // Held to 128 VGPRs (4 waves per SIMD): one more resident wave than the compiler's own choice hides more of
 // the queue loads and the compaction barrier than the few spilled values cost.
-template <int GROUPS, bool COUNT, bool PRIMARY, bool FLAT>
+// FAST (Scene::settle_fast): the media are plain spheres of plain colour, tested from the records in LDS.
+template <int GROUPS, bool COUNT, bool PRIMARY, bool FLAT, bool FAST = false>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 4 : BOUNCE_WAVES))) void k_bounce(Scene S, rtk::RenderConst rc, rtk::Batch batch, rtk::PathState in,
                                                         rtk::PathState out, rtk::Queues q, uint32_t bounce,
                                                         float4* __restrict__ radiance, unsigned long long* stats,
@@ -296,6 +413,8 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
     }
     const Stack stk{stack + threadIdx.x, S.stack_cap, nullptr, 0u};
     const LdsTables L = stage_tables(S, stack);
+    __shared__ FastLds fl;
+    if (FAST) fill_fast_lds(S, fl);
     TraceCount tc{0u, 0u, 0u, 0u, 0u};
     uint32_t parity = 0;
     // instrumented build only: wave cycles spent per section (s_memtime ticks), and wave tiles
@@ -318,8 +437,20 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(GROU
                 t0 = t1;
             }
             Hit h;
-            trace_ray<rtk::BLOCK, GROUPS, FLAT, COUNT>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk,
-                                                        overflow_flag, &tc);
+            trace_ray<rtk::BLOCK, GROUPS, FLAT, COUNT, !FAST>(S, p.o, p.d, p.time, 0.005f, INF_F, p.k0, p.k1, bounce, h, stk,
+                                                               overflow_flag, &tc);
+            if (FAST && ray_is_finite(p.o, p.d)) {  // apply_media from the records in LDS
+                const float a = dot3(p.d, p.d);
+                for (uint32_t m = 0; m < S.n_media; m++) {
+                    float tm;
+                    if (fast_medium(fl.m[m], p.o, p.d, a, 0.005f, p.k0, p.k1, bounce, h.t, tm)) {
+                        h.t = tm;
+                        h.prim = fl.m[m].hit;
+                        h.grp = -1;
+                        h.key = fl.m[m].key;
+                    }
+                }
+            }
             if (COUNT) {
                 asm volatile("" ::"v"(h.t), "v"(h.prim));
                 t1 = __builtin_amdgcn_s_memtime();
@@ -541,16 +672,19 @@ DEV float settle_next(const Scene& S, const PathRegs& p, uint32_t medium0, uint3
 // at the far end of its shard with that distance (a second count per shard, rtk::Queues), where the trace kernel does not
 // look; k_settled takes it from there.  Paths are tested when at least `entry_lanes` lanes of their wave qualify (the test
 // costs the wave the same for one lane as for 64).  Every path carries its own bounce number (see PathRegs).
-template <bool NESTED, bool SETTLE>
+// FAST (Scene::settle_fast; implies SETTLE, never NESTED): the media are tested and the next ray settled from the records in LDS.
+template <bool NESTED, bool SETTLE, bool FAST>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade(Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out,
                                                        const float4* __restrict__ hits, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ radiance, unsigned long long* stats, uint32_t entry_lanes,
                                                        uint32_t near_hits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // no traversal here: only the staged tables (launched with stack_cap = 0 in mind)
     __shared__ CompactLds clds;
+    __shared__ FastLds fl;
     Scene St = S;
     St.stack_cap = 0;
     const LdsTables L = stage_tables(St, stack);
+    if (FAST) fill_fast_lds(S, fl);
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
@@ -593,9 +727,23 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             h.prim = __float_as_uint(hv.y);
             h.grp = __float_as_int(hv.z);
             h.key = __float_as_uint(hv.w);
-            if (ray_is_finite(p.o, p.d))  // (as apply_media)
-                for (uint32_t m = 0; m < S.n_media; m++)
-                    test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, p.bounce, h);
+            if (ray_is_finite(p.o, p.d)) {  // (as apply_media)
+                if (FAST) {
+                    const float a = dot3(p.d, p.d);
+                    for (uint32_t m = 0; m < S.n_media; m++) {
+                        float tm;
+                        if (fast_medium(fl.m[m], p.o, p.d, a, 0.005f, p.k0, p.k1, p.bounce, h.t, tm)) {
+                            h.t = tm;
+                            h.prim = fl.m[m].hit;
+                            h.grp = -1;
+                            h.key = fl.m[m].key;
+                        }
+                    }
+                } else {
+                    for (uint32_t m = 0; m < S.n_media; m++)
+                        test_medium<NESTED>(S, S.media[m], p.o, p.d, p.time, 0.005f, p.k0, p.k1, p.bounce, h);
+                }
+            }
 #ifdef RT_HIST
             if (p.bounce >= 16u) {
                 uint32_t cls = 4u;
@@ -610,7 +758,8 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
             alive = shade_path<NESTED>(S, L, rc, p, h, p.bounce, radiance);
             candidate = alive && (h.prim == medium0 || h.prim == near_prim);
         }
-        if ((uint32_t)__popcll(__ballot(candidate)) >= entry_lanes && candidate) p.settled = settle_next<NESTED>(S, p, medium0, near_prim);
+        if ((uint32_t)__popcll(__ballot(candidate)) >= entry_lanes && candidate)
+            p.settled = FAST ? settle_next_fast(S, fl, p, near_prim) : settle_next<NESTED>(S, p, medium0, near_prim);
         compact_store2(clds, parity, alive && p.settled == 0.0f, alive && p.settled != 0.0f, p, out, out_count, out_settled, shard_base,
                        q.cap_shard);
     }
@@ -635,47 +784,6 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 // a step cannot do -- shade a hit on the primitive near the medium (glass: the whole material code) -- is left to the general
 // step, and lanes that need that one WAIT until `slow_min` of their wave do (or nothing else is left to do): run for two or
 // three lanes in every round it would cost each round more than the fast step itself.
-struct FastMedium {
-    float cx, cy, cz, r;
-    double neg_inv_density;
-    uint32_t salt, hit, key, pad;
-    float col[3];
-    float inv_density_lo;  // a float just below 1 / density (fast_medium_misses)
-};
-struct FastLds {
-    FastMedium m[4];
-    float blo[3], bhi[3];        // widened box of the first medium's boundary (Group::blo / bhi)
-    float ncx, ncy, ncz, nr;     // the one primitive near the first medium (a resting sphere of glass), if the scene has one
-    float near_ior;
-    uint32_t same_sphere;        // that sphere equals the first medium's boundary bit for bit (final_scene: main.rs:279-282)
-};
-// The free flight of such a medium once the roots of its sphere are known (test_medium's single-sphere case).
-DEV bool fast_medium_flight(const FastMedium& M, bool line_hits, float c0, float c1, float a, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce,
-                            float best_t, float& t) {
-    float r1, r2;
-    const uint32_t have = line_hits ? 3u : 0u;
-    if (!pick_root(have, c0, c1, -INF_F, INF_F, r1)) return false;
-    if (!pick_root(have, c0, c1, r1 + 0.0001f, INF_F, r2)) return false;
-    return medium_flight(r1, r2, tmin, best_t, (double)__builtin_sqrtf(a), M.neg_inv_density, medium_xi_salted(k0, k1, bounce, M.salt), t);
-}
-// ConstantMedium::intersect for such a medium: test_medium's single-sphere case with the record in LDS.
-DEV bool fast_medium(const FastMedium& M, f3 o, f3 d, float a, float tmin, uint32_t k0, uint32_t k1, uint32_t bounce, float best_t, float& t) {
-    float c0, c1;
-    const bool line_hits = sphere_roots(mk3(M.cx, M.cy, M.cz), M.r, o, d, a, c0, c1);
-    return fast_medium_flight(M, line_hits, c0, c1, a, tmin, k0, k1, bounce, best_t, t);
-}
-// true: fast_medium certainly returns false for a closest hit at best_t (> 0), whatever the sphere -- decided from the
-// medium's draw alone, in f32.  The medium takes a ray only if its flight -ln(xi) / density ends within the part of the ray
-// inside it, which is shorter than best_t / |d| (medium_flight: r1 >= tmin > 0, r2 <= best_t).  The hardware log2 of the
-// rounded draw is within 2e-7 relative and 6e-8 absolute of ln(xi) / ln 2; both sides carry that slack, so "misses" is never
-// said wrongly, and a draw of exactly 0 (flight +inf) misses.  For a thin medium this spares nearly every ray the f64
-// logarithm and the two f64 divisions.
-DEV bool fast_medium_misses(const FastMedium& M, float a, uint32_t k0, uint32_t k1, uint32_t bounce, float best_t) {
-    const float xi = (float)medium_xi_salted(k0, k1, bounce, M.salt);
-    const float flight_lo = M.inv_density_lo * (__builtin_amdgcn_logf(xi) * -0.69314647f - 2e-7f);  // (ln 2 rounded down a little)
-    const float inside_hi = best_t * __builtin_amdgcn_rsqf(a) * 1.000002f;
-    return flight_lo > inside_hi;
-}
 #ifndef SETTLED_WAVES
 #define SETTLED_WAVES 4
 #endif
@@ -695,52 +803,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETT
     const uint32_t shard_base = shard * q.cap_shard, lane = threadIdx.x & 63u;
     const uint32_t medium0 = HIT_MEDIUM_BIT | S.media[0];
     const uint32_t near_prim = (S.near0_ball && S.near0_n == 1u && near_hits) ? S.media[S.n_media] : 0x7FFFFFFFu;
-    if (FAST) {
-        if (threadIdx.x < S.n_media) {
-            const uint32_t g = S.media[threadIdx.x];
-            const Group& G = S.groups[g];
-            const float4 sph = *reinterpret_cast<const float4*>(S.prims + (G.root_ref & 0x03FFFFFFu));
-            const Material& M = S.mats[G.mat];
-            FastMedium& F = fl.m[threadIdx.x];
-            F.cx = sph.x;
-            F.cy = sph.y;
-            F.cz = sph.z;
-            F.r = sph.w;
-            F.neg_inv_density = G.neg_inv_density;
-            F.salt = medium_salt(G.order);
-            F.hit = HIT_MEDIUM_BIT | g;
-            F.key = MEDIUM_KEY_BASE + G.order;
-            F.col[0] = M.albedo[0];
-            F.col[1] = M.albedo[1];
-            F.col[2] = M.albedo[2];
-            F.inv_density_lo = (float)(-G.neg_inv_density) * 0.9999995f;
-            if (threadIdx.x == 0u)
-                for (int k = 0; k < 3; k++) {
-                    fl.blo[k] = G.blo[k];
-                    fl.bhi[k] = G.bhi[k];
-                }
-        }
-        if (threadIdx.x == 64u) {
-            float4 sph = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float ior = 1.0f;
-            uint32_t same = 0u;
-            if (S.near0_n == 1u) {
-                const float4* rec = reinterpret_cast<const float4*>(S.prims + S.media[S.n_media]);
-                sph = rec[0];
-                ior = S.mats[__float_as_uint(rec[1].y) >> 8].ior;
-                const float4 b = *reinterpret_cast<const float4*>(S.prims + (S.groups[S.media[0]].root_ref & 0x03FFFFFFu));
-                same = (__float_as_uint(b.x) == __float_as_uint(sph.x) && __float_as_uint(b.y) == __float_as_uint(sph.y) &&
-                        __float_as_uint(b.z) == __float_as_uint(sph.z) && __float_as_uint(b.w) == __float_as_uint(sph.w)) ? 1u : 0u;
-            }
-            fl.ncx = sph.x;
-            fl.ncy = sph.y;
-            fl.ncz = sph.z;
-            fl.nr = sph.w;
-            fl.near_ior = ior;
-            fl.same_sphere = same;
-        }
-        __syncthreads();
-    }
+    if (FAST) fill_fast_lds(S, fl);
     // runs of at least min_run paths: a wave refills from its own run only, and a short run ends in a long, thin drain
     const uint32_t nw = stride * (rtk::BLOCK / 64u), wi = j0 * (rtk::BLOCK / 64u) + (threadIdx.x >> 6);
     uint32_t per = (((n + nw - 1u) / nw) + 63u) & ~63u;
@@ -875,33 +938,8 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETT
                     }
                     RT_SECTION(2, "v"(p.o.x), "v"(p.d.x), "v"(p.T.x));
                     if (have) {
-                        // settle_next with the records in LDS
-                        const f3 c0 = mk3(fl.m[0].cx, fl.m[0].cy, fl.m[0].cz);
-                        const float rr = fl.m[0].r * 1.0005f;
-                        const f3 oc = p.o - c0;
-                        const bool inside = p.o.x >= fl.blo[0] && p.o.x <= fl.bhi[0] && p.o.y >= fl.blo[1] && p.o.y <= fl.bhi[1] &&
-                                            p.o.z >= fl.blo[2] && p.o.z <= fl.bhi[2] && dot3(oc, oc) <= rr * rr;
-                        float s = 0.0f;
-                        if (inside) {
-                            const float a2 = dot3(p.d, p.d);
-                            float q0, q1, tg = INF_F, tm;
-                            const bool line_hits = sphere_roots(c0, fl.m[0].r, p.o, p.d, a2, q0, q1);
-                            bool hit_g = false;
-                            if (S.near0_n == 1u) {
-                                // (the same sphere: its roots are the boundary's -- quotient_pair gives the quotients of
-                                // sphere_candidate bit for bit -- and the root it takes is pick_root's)
-                                if (fl.same_sphere) hit_g = pick_root(line_hits ? 3u : 0u, q0, q1, 0.005f, INF_F, tg);
-                                else hit_g = sphere_candidate(mk3(fl.ncx, fl.ncy, fl.ncz), fl.nr, p.o, p.d, a2, 0.005f, INF_F, tg);
-                            }
-                            if (fast_medium_flight(fl.m[0], line_hits, q0, q1, a2, 0.005f, p.k0, p.k1, p.bounce, hit_g ? tg : INF_F, tm)) {
-                                if (tm > 0.0f) s = tm;
-                            } else if (hit_g && tg > 0.0f && near_prim != 0x7FFFFFFFu) {
-                                const f3 pc = (p.o + tg * p.d) - c0;
-                                if (dot3(pc, pc) <= rr * rr) s = -tg;
-                            }
-                        }
-                        p.settled = s;
-                        have = s != 0.0f;
+                        p.settled = settle_next_fast(S, fl, p, near_prim);
+                        have = p.settled != 0.0f;
                         leaving = !have;
                     }
                     RT_SECTION(3, "v"(p.settled));
@@ -1311,15 +1349,16 @@ hipError_t launch_shade(hipStream_t s, const Tuning& tn, const Scene& scene, con
     const uint32_t entry_lanes = std::min(64u, std::max(1u, tn.settle_entry));
     const bool settle = may_settle && scene_settles(scene);
     const uint32_t near_hits = tn.settle_near_hits;
-#define RT_SHADE(N, T)                                                                                                              \
-    hipLaunchKernelGGL((k_shade<N, T>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<N, T>, tn.oversub, smem)), \
+#define RT_SHADE(N, T, F)                                                                                                                 \
+    hipLaunchKernelGGL((k_shade<N, T, F>), dim3(grid_sharded(blocks_per_shard, (const void*)&k_shade<N, T, F>, tn.oversub, smem)), \
                        dim3(BLOCK), smem, s, scene, rc, in, out, hits, q, bounce, radiance, stats, entry_lanes, near_hits)
     if (scene.nested) {
-        if (settle) RT_SHADE(true, true);
-        else RT_SHADE(true, false);
+        if (settle) RT_SHADE(true, true, false);
+        else RT_SHADE(true, false, false);
     } else {
-        if (settle) RT_SHADE(false, true);
-        else RT_SHADE(false, false);
+        if (settle && scene.settle_fast && tn.settled_fast) RT_SHADE(false, true, true);
+        else if (settle) RT_SHADE(false, true, false);
+        else RT_SHADE(false, false, false);
     }
 #undef RT_SHADE
     return hipGetLastError();
@@ -1349,7 +1388,11 @@ hipError_t launch_bounce(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, c
                          unsigned long long* stats, uint32_t* overflow_flag) {
     const dim3 block(BLOCK);
     const size_t smem = stack_bytes(scene) + table_bytes(scene);
-    if (bounce == 0) {
+    if (bounce == 0 && scene.settle_fast && tn.settled_fast && cfg.has_groups && !cfg.count_visits && !cfg.nested && !scene.flat) {
+        hipLaunchKernelGGL((k_bounce<1, false, true, false, true>),
+                           dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<1, false, true, false, true>, tn.oversub, smem)), block, smem, s,
+                           scene, rc, batch, in, out, q, bounce, radiance, stats, overflow_flag);
+    } else if (bounce == 0) {
 #define RT_CALL(G, C, F)                                                                                                  \
     hipLaunchKernelGGL((k_bounce<G, C, true, F>),                                                                         \
                        dim3(grid_sharded(blocks_per_shard, (const void*)&k_bounce<G, C, true, F>, tn.oversub, smem)), block, \
