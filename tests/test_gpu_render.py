@@ -558,6 +558,60 @@ def test_settling_the_first_medium_ahead_changes_no_bit(name, monkeypatch):
         assert rays == out[0][1] and np.array_equal(img, out[0][0])
 
 
+@pytest.mark.parametrize("glass, n_media", [(False, 1), (False, 3), (True, 2), (True, 4)])
+def test_settled_paths_in_raw_scenes_of_sphere_shaped_media(glass, n_media, monkeypatch):
+    """The step of k_settled that is specialised for sphere-shaped media of plain colour, on scenes sent through the raw ABI:
+    a dense ball of medium among sixty diffuse spheres (a tree, not a flat scene), with or without a shell of glass of the
+    same radius around it, alone or together with a thin fog around everything and further balls of medium elsewhere (up
+    to four media).  Settling ahead on or off, the specialised step on or off: same image bits, same ray count; and with
+    it on, a good share of the rays never sees the tree."""
+    rng = np.random.default_rng(7)
+    c0r, mat, group = [], [], []
+    for _ in range(60):  # diffuse spheres on a ring around the ball, clear of it
+        ang, rad = rng.uniform(0, 2 * math.pi), rng.uniform(60, 120)
+        c0r.append([rad * math.cos(ang), rng.uniform(-20, 20), rad * math.sin(ang), rng.uniform(2, 6)])
+        mat.append(0)
+        group.append(0)
+    texs = [rtamd.rt_texture(kind=0, color=(C.c_float * 3)(0.7, 0.6, 0.5)), rtamd.rt_texture(kind=0, color=(C.c_float * 3)(0.2, 0.4, 0.9)),
+            rtamd.rt_texture(kind=0, color=(C.c_float * 3)(1, 1, 1)), rtamd.rt_texture(kind=0, color=(C.c_float * 3)(0.9, 0.3, 0.3))]
+    mats = [rtamd.rt_material(kind=0, tex=0), rtamd.rt_material(kind=2, ior=1.5), rtamd.rt_material(kind=4, tex=1),
+            rtamd.rt_material(kind=4, tex=2), rtamd.rt_material(kind=4, tex=3)]
+    groups = []
+    media = [([0, 0, 0, 30], 0.3, 2), ([0, 0, 0, 800], 0.002, 3), ([90, 0, 0, 12], 0.5, 4), ([-90, 5, 10, 15], 0.2, 4)][:n_media]
+    if glass:
+        c0r.append([0, 0, 0, 30])
+        mat.append(1)
+        group.append(0)
+    for k, (sph, density, m) in enumerate(media):
+        groups.append(rtamd.rt_group(kind=2, has_xform=0, neg_inv_density=-1.0 / density, mat=m))
+        c0r.append(sph)
+        mat.append(0)
+        group.append(k + 1)
+    spheres = dict(c0r=c0r, mat=mat, id=list(range(len(c0r))), group=group)
+    cam = rtamd.camera_new((0, 10, -150), (0, 0, 0), (0, 1, 0), math.radians(35), 1.0, 0.0, 10.0, 0.0, 1.0)
+    w = h = 160
+    spp = 16
+    out = []
+    for case in (dict(RTAMD_SETTLE_AHEAD="0"), dict(), dict(RTAMD_SETTLED_FAST="0"), dict(RTAMD_SETTLED_SLOW_MIN="1", RTAMD_SETTLED_MIN_RUN="64")):
+        for k in ("RTAMD_SETTLE_AHEAD", "RTAMD_SETTLED_FAST", "RTAMD_SETTLED_SLOW_MIN", "RTAMD_SETTLED_MIN_RUN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in case.items():
+            monkeypatch.setenv(k, v)
+        ctx = rtamd.Context(0)
+        info = ctx.set_scene(spheres=spheres, groups=groups, materials=mats, textures=texs)
+        assert info["n_nodes"] > 20 and info["n_media"] == n_media
+        ctx.set_tail_paths(0)  # (a frame this small would otherwise be finished by the tail kernel after the first bounce)
+        for pipe in (0, 2):
+            ctx.set_pipeline(pipe)
+            img, st = ctx.render(w, h, cam, spp, background=(0.6, 0.7, 0.9), seed=3)
+            assert ((st["settled_rays"] > 0.03 * st["rays"]) if case.get("RTAMD_SETTLE_AHEAD", "1") == "1" else st["settled_rays"] == 0), (st["settled_rays"], st["rays"])
+            out.append((img, st["rays"]))
+        ctx.close()
+    assert np.isfinite(out[0][0]).all() and out[0][0].sum() > 0
+    for img, rays in out[1:]:
+        assert rays == out[0][1] and np.array_equal(img, out[0][0])
+
+
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "two_spheres", "simple_light"])
 def test_flat_and_tree_tracing_give_the_same_bits(name, monkeypatch):
     """Scenes of a few dozen primitives are traced without the tree (uniform loops over the primitives).  The
