@@ -503,6 +503,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     tn.settled_min_run = knob("RTAMD_SETTLED_MIN_RUN", tn.settled_min_run, 64, 1 << 20);
     tn.settled_slow_min = knob("RTAMD_SETTLED_SLOW_MIN", tn.settled_slow_min, 1, 64);
     tn.settled_fast = knob("RTAMD_SETTLED_FAST", tn.settled_fast, 0, 1);
+    tn.settled_late_rounds = knob("RTAMD_SETTLED_LATE_ROUNDS", tn.settled_late_rounds, 1, 255);
     tn.settled_drain = knob("RTAMD_SETTLED_DRAIN", tn.settled_drain, 1, 64);
     tn.settled_oversub = knob("RTAMD_SETTLED_OVERSUB", tn.settled_oversub, 1, 64);
     *out = c;

@@ -77,6 +77,7 @@ struct Tuning {
     int settled_refill = 16;        // RTAMD_SETTLED_REFILL: idle lanes at which a wave of k_settled takes new paths
     int settled_min_run = 128;      // RTAMD_SETTLED_MIN_RUN: fewest paths a wave of k_settled is given
     int settled_drain = 24;         // RTAMD_SETTLED_DRAIN: a wave of k_settled whose run is used up hands its paths on once fewer are left
+    int settled_late_rounds = 2;    // RTAMD_SETTLED_LATE_ROUNDS: rounds a wave of k_settled may still run once its run is used up
     int settled_slow_min = 4;       // RTAMD_SETTLED_SLOW_MIN: lanes of a wave of k_settled that must wait for the general step before it runs
     int settled_fast = 1;           // RTAMD_SETTLED_FAST=0: never the step specialised for sphere-shaped media (Scene::settle_fast)
     int settled_oversub = 1;        // RTAMD_SETTLED_OVERSUB: grid of k_settled, in rounds of resident blocks

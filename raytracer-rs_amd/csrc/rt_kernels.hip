@@ -790,24 +790,27 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 template <bool NESTED, bool FAST>
 __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETTLED_WAVES))) void k_settled(
     Scene S, rtk::RenderConst rc, rtk::PathState in, rtk::PathState out, rtk::Queues q, uint32_t bounce, float4* __restrict__ radiance,
-    unsigned long long* stats, uint32_t REFILL, uint32_t min_run, uint32_t DRAIN, uint32_t near_hits, uint32_t slow_min) {
+    unsigned long long* stats, uint32_t REFILL, uint32_t min_run, uint32_t DRAIN, uint32_t near_hits, uint32_t slow_min, uint32_t late_max) {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // only the staged tables
     __shared__ FastLds fl;
+    const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
+    const uint32_t n = q.counts[(3u + bounce % 3u) * rtk::NSHARD + shard];
+    // runs of at least min_run paths: a wave refills from its own run only, and a short run ends in a long, thin drain
+    const uint32_t nw = stride * (rtk::BLOCK / 64u), wi = j0 * (rtk::BLOCK / 64u) + (threadIdx.x >> 6);
+    uint32_t per = (((n + nw - 1u) / nw) + 63u) & ~63u;
+    if (per < min_run) per = min_run;
+    // (the grid is sized for a full queue; most launches late in a batch find a few paths per shard, and a block none of
+    // whose waves gets a run leaves before it stages anything)
+    if ((unsigned long long)j0 * (rtk::BLOCK / 64u) * per >= n) return;
     Scene St = S;
     St.stack_cap = 0;
     const LdsTables L = stage_tables(St, stack);
-    const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
-    const uint32_t n = q.counts[(3u + bounce % 3u) * rtk::NSHARD + shard];
     uint32_t* out_count = q.counts + ((bounce + 1u) % 3u) * rtk::NSHARD + shard;
     uint32_t* out_settled = q.counts + (3u + (bounce + 1u) % 3u) * rtk::NSHARD + shard;
     const uint32_t shard_base = shard * q.cap_shard, lane = threadIdx.x & 63u;
     const uint32_t medium0 = HIT_MEDIUM_BIT | S.media[0];
     const uint32_t near_prim = (S.near0_ball && S.near0_n == 1u && near_hits) ? S.media[S.n_media] : 0x7FFFFFFFu;
     if (FAST) fill_fast_lds(S, fl);
-    // runs of at least min_run paths: a wave refills from its own run only, and a short run ends in a long, thin drain
-    const uint32_t nw = stride * (rtk::BLOCK / 64u), wi = j0 * (rtk::BLOCK / 64u) + (threadIdx.x >> 6);
-    uint32_t per = (((n + nw - 1u) / nw) + 63u) & ~63u;
-    if (per < min_run) per = min_run;
     const unsigned long long first = (unsigned long long)wi * per;
     uint32_t next = __builtin_amdgcn_readfirstlane(first < n ? (uint32_t)first : n);
     const uint32_t end = __builtin_amdgcn_readfirstlane(n - next > per ? next + per : n);
@@ -818,8 +821,9 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETT
     p.o = p.d = p.T = mk3(0.0f, 0.0f, 0.0f);
     p.time = 0.0f;
     p.k0 = p.k1 = p.slot = 0u;
-    uint32_t rays = 0, taken = 0;
-    const uint32_t drain = bounce + 1u >= rc.max_depth ? 1u : DRAIN;
+    uint32_t rays = 0, taken = 0, late_rounds = 0;
+    const bool last_launch = bounce + 1u >= rc.max_depth;
+    const uint32_t drain = last_launch ? 1u : DRAIN;
 #ifdef RT_SECTIONS  // wave cycles per section of the loop (s_memtime), summed into stats[24..28]; [29] counts loop rounds
     unsigned long long cyc[5] = {0, 0, 0, 0, 0}, rounds = 0, t0 = 0, t1 = 0;
 #define RT_SECTION(k, ...) do { asm volatile("" :: __VA_ARGS__); t1 = __builtin_amdgcn_s_memtime(); cyc[k] += t1 - t0; t0 = t1; } while (0)
@@ -839,7 +843,11 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(SETT
             // fewer than DRAIN paths left it hands them on, still settled, to the far end of `out`, where the next launch of
             // this kernel finds them next to the paths k_shade has settled meanwhile.  (Not in the last launch of a batch, which
             // nothing follows: there every path is at the depth limit and ends with its next step.)
-            if ((!more && n_idle > 64u - drain) || (more && n_idle >= REFILL)) {
+            // A wave also hands on, however many paths it holds, `late_max` rounds after its run was used up: a small launch
+            // (a few paths per shard, late in a batch or on one rank's share of a frame) is a chain of serial rounds on a
+            // nearly empty GPU, and the next launch comes anyway.
+            if (!more) late_rounds++;
+            if ((!more && (n_idle > 64u - drain || (late_rounds > late_max && !last_launch))) || (more && n_idle >= REFILL)) {
                 const unsigned long long out_mask = __ballot(leaving);
                 if (out_mask) {
                     uint32_t at = 0;
@@ -1375,7 +1383,8 @@ hipError_t launch_settled(hipStream_t s, const Tuning& tn, const Scene& scene, c
     const uint32_t slow_min = (uint32_t)std::min(64, std::max(1, tn.settled_slow_min));
 #define RT_SETTLED(N, F)                                                                                                                      \
     hipLaunchKernelGGL((k_settled<N, F>), dim3(grid_sharded(MAX_BLOCKS_PER_SHARD, (const void*)&k_settled<N, F>, tn.settled_oversub, smem)), \
-                       dim3(BLOCK), smem, s, scene, rc, in, out, q, bounce, radiance, stats, refill, min_run, drain, tn.settle_near_hits, slow_min)
+                       dim3(BLOCK), smem, s, scene, rc, in, out, q, bounce, radiance, stats, refill, min_run, drain, tn.settle_near_hits, slow_min, \
+                       (uint32_t)std::max(1, tn.settled_late_rounds))
     if (scene.nested) RT_SETTLED(true, false);
     else if (scene.settle_fast && tn.settled_fast) RT_SETTLED(false, true);
     else RT_SETTLED(false, false);

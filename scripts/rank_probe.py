@@ -12,6 +12,7 @@ cam = ctx.preset_camera(aspect)
 acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
 ctx.render(w, h, cam, spp, accum=acc, rank=rank, nranks=nranks)
 torch.cuda.synchronize()
+ctx.profile(events=True)
 best = 1e9
 for _ in range(reps):
     t0 = time.perf_counter()
@@ -19,4 +20,5 @@ for _ in range(reps):
     best = min(best, time.perf_counter() - t0)
 dt = best
 if True:
-    print(f"{name} rank {rank}/{nranks}: {dt*1e3:.2f} ms, {st['rays']/dt/1e6:.0f} Mrays/s, launches {st['bounce_launches']}", flush=True)
+    print(f"{name} rank {rank}/{nranks}: {dt*1e3:.2f} ms, {st['rays']/dt/1e6:.0f} Mrays/s, launches {st['bounce_launches']} | trace {st['trace_ms']:.2f} shade {st['shade_ms']:.2f} "
+          f"settled {st.get('settled_ms', 0):.2f} bounce {st['bounce_ms']:.2f} tail {st['tail_ms']:.2f} accum {st['accumulate_ms']:.2f}", flush=True)

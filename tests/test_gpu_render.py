@@ -533,11 +533,12 @@ def test_settling_the_first_medium_ahead_changes_no_bit(name, monkeypatch):
     out = []
     cases = [dict(RTAMD_SETTLE_AHEAD="0"), dict(RTAMD_SETTLE_ENTRY="1"), dict(), dict(RTAMD_SETTLED_FAST="0"),
              dict(RTAMD_SETTLED_SLOW_MIN="1"), dict(RTAMD_SETTLED_SLOW_MIN="40", RTAMD_SETTLED_REFILL="4"),
-             dict(RTAMD_SETTLED_MIN_RUN="64", RTAMD_SETTLED_DRAIN="60"), dict(RTAMD_SETTLED_DRAIN="1", RTAMD_SETTLE_NEAR_HITS="0"),
+             dict(RTAMD_SETTLED_MIN_RUN="64", RTAMD_SETTLED_DRAIN="60"), dict(RTAMD_SETTLED_DRAIN="1", RTAMD_SETTLE_NEAR_HITS="0", RTAMD_SETTLED_LATE_ROUNDS="200"),
+             dict(RTAMD_SETTLED_LATE_ROUNDS="1"),
              dict(tail=20000)]
     for case in cases:
         for k in ("RTAMD_SETTLE_AHEAD", "RTAMD_SETTLE_ENTRY", "RTAMD_SETTLED_FAST", "RTAMD_SETTLED_SLOW_MIN", "RTAMD_SETTLED_REFILL",
-                  "RTAMD_SETTLED_MIN_RUN", "RTAMD_SETTLED_DRAIN", "RTAMD_SETTLE_NEAR_HITS"):
+                  "RTAMD_SETTLED_MIN_RUN", "RTAMD_SETTLED_DRAIN", "RTAMD_SETTLE_NEAR_HITS", "RTAMD_SETTLED_LATE_ROUNDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in case.items():
             if k.startswith("RTAMD_"):
