@@ -1,4 +1,5 @@
-"""rt_intersect_batch_noalloc -- the entry point that allocates nothing -- against rt_intersect_batch, through the C ABI.
+"""rt_intersect_batch_noalloc -- the entry point that allocates nothing -- against rt_intersect_batch and against the oracle,
+through the C ABI.
 
 Its kernels take the overflow flag, and for host callers the staging of rays and results, from a static device array
 whose address the library looks up once per device (hipGetSymbolAddress); every call on a GPU shares that array, which
@@ -41,6 +42,13 @@ def test_no_alloc_entry_point_matches_the_allocating_one(name):
         part = ctx.intersect(r, seed=3, noalloc=True, outputs=("prim", "t"))
         assert np.array_equal(part["prim"], ref["prim"]) and np.array_equal(part["t"], ref["t"], equal_nan=True)
     assert (ref["prim"] != -1).mean() > 0.3
+    # ... and against the oracle directly (not only against the allocating entry point): ids bit for bit, t and normals to 1e-5
+    oref = orc.Scene(name, seed=1).intersect(np.ascontiguousarray(rays[:, :n_big]), seed=3, mode=1)
+    got = ctx.intersect(np.ascontiguousarray(rays[:, :n_big]), seed=3, noalloc=True)
+    assert np.array_equal(got["prim"], oref["prim"]) and np.array_equal(got["inst"], oref["inst"])
+    hit = oref["prim"] != -1
+    np.testing.assert_allclose(got["t"][hit], oref["t"][hit], rtol=1e-5)
+    np.testing.assert_allclose(got["normal"][hit], oref["normal"][hit], atol=1e-5)
     # repeated calls leave the device's free memory where it was (torch's own tensors aside: same sizes every time)
     for _ in range(3):
         ctx.intersect(rays[:, :n_small].copy(), seed=3, noalloc=True)
