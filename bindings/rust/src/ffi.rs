@@ -181,6 +181,7 @@ extern "C" {
     pub fn rt_resolve_u8_transfer(ctx: *mut rt_ctx, sum_rgb: *const f32, n_pixels: u64, spp: u32, transfer: c_int,
                                   out: *mut u8) -> c_int;
     pub fn rt_image_write(path: *const c_char, width: u32, height: u32, rgb: *const u8, format: c_int) -> c_int;
+    pub fn rt_image_read(path: *const c_char, width: *mut u32, height: *mut u32, rgb: *mut u8, cap_bytes: u64) -> c_int;
     pub fn rt_accum_write(path: *const c_char, width: u32, height: u32, samples_done: u32, seed: u32,
                           accum_rgb: *const f32) -> c_int;
     pub fn rt_accum_read(path: *const c_char, width: *mut u32, height: *mut u32, samples_done: *mut u32, seed: *mut u32,

@@ -283,6 +283,14 @@ int rt_resolve_u8_transfer(rt_ctx* ctx, const float* sum_rgb, uint64_t n_pixels,
  * row 0 = top, as an 8-bit RGB PNG or a binary PPM (P6). */
 typedef enum rt_image_format { RT_IMAGE_PNG = 0, RT_IMAGE_PPM = 1 } rt_image_format;
 int rt_image_write(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb, int format);
+/* ---- texture files (host only; no GPU needed) -----------------------------------------
+ * Stands in for ImageTexture::new (texture.rs:89-93: image::open(path).unwrap().into_rgb8()): decodes a baseline
+ * JPEG (8 bit, Huffman; greyscale or YCbCr with chroma sampled 1x1, 2x1 or 2x2; restart markers) or a binary PPM
+ * into height x width x 3 bytes, row 0 = top -- the layout rt_scene_desc's images take.  With rgb == NULL only
+ * *width and *height are set; otherwise cap_bytes must hold width*height*3.  A missing file is RT_ERR_IO, a format
+ * outside the above (progressive or arithmetic-coded JPEG, PNG, ...) RT_ERR_UNSUPPORTED where the reference panics.
+ * The decode follows libjpeg's default arithmetic (accurate integer IDCT, triangle-filter chroma upsampling). */
+int rt_image_read(const char* path, uint32_t* width, uint32_t* height, uint8_t* rgb, uint64_t cap_bytes);
 /* Checkpoint of a progressive render (the reference has none; its render is all-or-nothing): the f32 sample
  * sums (host, height x width x 3) together with the number of samples they hold and the seed.  Continue with
  * rt_render(sample0 = samples_done, ...) into the loaded buffer: the result equals the uninterrupted render

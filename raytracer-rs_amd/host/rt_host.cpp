@@ -389,6 +389,28 @@ int rth_scene_flatten_counts(void* h, int64_t info[12], int* ids_ok, char* err, 
     }
 }
 
+// The index-th image the flattened scene would hand to rt_scene_set_image (host-logic checks of ImageTexture::new):
+// sets *w, *h and copies w*h*3 bytes when rgb is given and cap is large enough.
+int rth_scene_flattened_image(void* h, uint32_t index, uint32_t* w, uint32_t* hgt, uint8_t* rgb, uint64_t cap) {
+    Built* b = static_cast<Built*>(h);
+    if (!b || !w || !hgt) return RT_ERR_INVALID;
+    try {
+        FlatScene fs;
+        b->world.flatten(fs, 0);
+        if (index >= fs.images.size()) return RT_ERR_INVALID;
+        const auto& im = fs.images[index];
+        *w = im.w;
+        *hgt = im.h;
+        if (rgb) {
+            if (cap < im.rgb.size()) return RT_ERR_INVALID;
+            std::memcpy(rgb, im.rgb.data(), im.rgb.size());
+        }
+        return RT_OK;
+    } catch (const std::exception&) {
+        return RT_ERR_UNSUPPORTED;
+    }
+}
+
 // cam[0..2] origin, [3..5] target, [6] vfov in degrees, [7] aperture, [8..10] background
 void rth_scene_preset(void* h, float cam[11]) {
     const Preset& p = static_cast<Built*>(h)->preset;

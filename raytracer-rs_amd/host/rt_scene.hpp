@@ -350,25 +350,17 @@ struct NoiseTexture : Texture {
 struct ImageTexture : Texture {
     uint32_t width = 0, height = 0;
     std::vector<uint8_t> rgb;
-    // texture.rs:89-93 decodes any format the `image` crate knows and panics on failure; this build has
-    // no JPEG decoder, so it reads a binary PPM (P6, maxval 255) and throws instead of panicking.
+    // texture.rs:89-93 decodes any format the `image` crate knows and panics on failure; rt_image_read knows
+    // baseline JPEG (what the reference's earthmap.jpg is) and binary PPM, and this throws instead of panicking.
     static ImageTexture new_(const std::string& path) {
         ImageTexture t;
-        FILE* f = std::fopen(path.c_str(), "rb");
-        if (!f) throw std::runtime_error("ImageTexture: cannot open " + path);
-        char magic[3] = {0, 0, 0};
-        int w = 0, h = 0, maxv = 0;
-        bool ok = std::fscanf(f, "%2s %d %d %d", magic, &w, &h, &maxv) == 4 && std::strcmp(magic, "P6") == 0 && maxv == 255 &&
-                  w > 0 && h > 0;
-        if (ok) {
-            std::fgetc(f);  // single whitespace after maxval
-            t.rgb.resize((size_t)w * h * 3);
-            ok = std::fread(t.rgb.data(), 1, t.rgb.size(), f) == t.rgb.size();
+        int rc = rt_image_read(path.c_str(), &t.width, &t.height, nullptr, 0);
+        if (rc == RT_OK) {
+            t.rgb.resize((size_t)t.width * t.height * 3);
+            rc = rt_image_read(path.c_str(), &t.width, &t.height, t.rgb.data(), t.rgb.size());
         }
-        std::fclose(f);
-        if (!ok) throw std::runtime_error("ImageTexture: not a binary 8-bit PPM: " + path);
-        t.width = (uint32_t)w;
-        t.height = (uint32_t)h;
+        if (rc == RT_ERR_IO) throw std::runtime_error("ImageTexture: cannot open " + path);
+        if (rc != RT_OK) throw std::runtime_error("ImageTexture: neither a baseline JPEG nor a binary 8-bit PPM: " + path);
         return t;
     }
     uint32_t emit(FlatScene& fs) const override {

@@ -25,7 +25,7 @@ SCENES = ("random_world", "two_spheres", "two_perlin_spheres", "earth", "simple_
 
 RT_OK = 0
 STATUS = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_HIP", -3: "RT_ERR_UNSUPPORTED", -4: "RT_ERR_NOT_COMMITTED",
-          -5: "RT_ERR_NO_DEVICE"}
+          -5: "RT_ERR_NO_DEVICE", -6: "RT_ERR_IO"}
 
 # every symbol include/rtamd.h declares
 ABI_SYMBOLS = (
@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "rt_ctx_synchronize", "rt_ctx_set_pipeline", "rt_ctx_set_tail_paths", "rt_ctx_reserve", "rt_ctx_set_builder", "rt_ctx_set_bvh_width", "rt_ctx_set_fuse_boxes", "rt_scene_read_bvh", "rt_scene_clear", "rt_scene_set_spheres", "rt_scene_set_rects", "rt_scene_set_groups",
     "rt_scene_set_materials", "rt_scene_set_textures", "rt_scene_set_perlin", "rt_scene_set_image",
     "rt_scene_commit", "rt_scene_get_info", "rt_intersect_batch", "rt_intersect_batch_noalloc", "rt_render", "rt_profile_enable",
-    "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_accum_write", "rt_accum_read", "rt_accum_write_tagged",
+    "rt_resolve_u8", "rt_resolve_u8_transfer", "rt_image_write", "rt_image_read", "rt_accum_write", "rt_accum_read", "rt_accum_write_tagged",
     "rt_accum_read_tagged", "rt_owned_pixels", "rt_comm_unique_id", "rt_comm_create", "rt_comm_attach", "rt_comm_destroy",
     "rt_gather_frame", "rt_frame_block_pixels", "rt_pack_owned", "rt_scatter_gathered")
 
@@ -148,6 +148,7 @@ def core():
     L.rt_resolve_u8.argtypes = [vp, vp, u64, u32, vp]
     L.rt_resolve_u8_transfer.argtypes = [vp, vp, u64, u32, C.c_int, vp]
     L.rt_image_write.argtypes = [C.c_char_p, u32, u32, vp, C.c_int]
+    L.rt_image_read.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp, u64]
     L.rt_accum_write.argtypes = [C.c_char_p, u32, u32, u32, u32, vp]
     L.rt_accum_read.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, u64]
     L.rt_accum_write_tagged.argtypes = [C.c_char_p, u32, u32, u32, u32, u64, vp]
@@ -187,6 +188,8 @@ def host():
     H.rth_scene_flatten_counts.restype = C.c_int
     H.rth_scene_preset.argtypes = [vp, C.POINTER(C.c_float)]
     H.rth_scene_preset.restype = None
+    H.rth_scene_flattened_image.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp, C.c_uint64]
+    H.rth_scene_flattened_image.restype = C.c_int
     H.rth_scene_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     H.rth_scene_counts.restype = None
     H.rth_scene_camera.argtypes = [vp, C.c_float, C.POINTER(rt_camera)]
@@ -297,6 +300,27 @@ def flatten_counts(name, seed=1, n_synth=0, earthmap=None):
         H.rth_scene_destroy(C.c_void_p(h))
 
 
+def flattened_image(name, index=0, seed=1, earthmap=None):
+    """The index-th image texture of a named scene as the C++ mirror decoded it: (h, w, 3) uint8 (no GPU needed)."""
+    H = host()
+    err = C.create_string_buffer(512)
+    h = H.rth_scene_build(name.encode(), seed, str(earthmap or EARTHMAP).encode(), 0, err, len(err))
+    if not h:
+        raise RtError(-1, err.value.decode())
+    try:
+        w, hh = C.c_uint32(), C.c_uint32()
+        rc = H.rth_scene_flattened_image(C.c_void_p(h), index, C.byref(w), C.byref(hh), None, 0)
+        if rc:
+            raise RtError(rc, "rth_scene_flattened_image")
+        a = np.empty((hh.value, w.value, 3), dtype=np.uint8)
+        rc = H.rth_scene_flattened_image(C.c_void_p(h), index, C.byref(w), C.byref(hh), a.ctypes.data, a.nbytes)
+        if rc:
+            raise RtError(rc, "rth_scene_flattened_image")
+        return a
+    finally:
+        H.rth_scene_destroy(C.c_void_p(h))
+
+
 def write_image(path, rgb8, fmt="png"):
     """(h, w, 3) uint8, row 0 = top -> PNG or binary PPM (stands in for main.rs:486-497)."""
     a = np.ascontiguousarray(rgb8.cpu().numpy() if _is_torch(rgb8) else rgb8, dtype=np.uint8)
@@ -306,6 +330,20 @@ def write_image(path, rgb8, fmt="png"):
     rc = core().rt_image_write(str(path).encode(), w, h, a.ctypes.data, {"png": 0, "ppm": 1}[fmt])
     if rc:
         raise RtError(rc, f"rt_image_write({path})")
+
+
+def read_image(path):
+    """Baseline JPEG or binary PPM -> (h, w, 3) uint8, row 0 = top: what ImageTexture::new(path) holds
+    (texture.rs:89-93).  Decoded by the library on the host."""
+    w, h = C.c_uint32(), C.c_uint32()
+    rc = core().rt_image_read(str(path).encode(), C.byref(w), C.byref(h), None, 0)
+    if rc:
+        raise RtError(rc, f"rt_image_read({path})")
+    a = np.empty((h.value, w.value, 3), dtype=np.uint8)
+    rc = core().rt_image_read(str(path).encode(), C.byref(w), C.byref(h), a.ctypes.data, a.nbytes)
+    if rc:
+        raise RtError(rc, f"rt_image_read({path})")
+    return a
 
 
 def save_accum(path, accum, samples_done, seed, tag=0):

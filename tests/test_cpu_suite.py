@@ -347,6 +347,82 @@ def test_image_write_png_and_ppm_round_trip(tmp_path):
         rtamd.write_image(tmp_path / "no_such_dir" / "a.png", img, "png")
 
 
+# ---- texture files (host only) -------------------------------------------------------------------------
+def _smooth_noise(rng, h, w):
+    """Something photograph-like: low-frequency colour plus a little noise (pure noise clips everywhere)."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 100 * np.sin(x / 7.0 + c) * np.cos(y / 5.0 - c) for c in range(3)], axis=-1)
+    return np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (2, 2), (16, 1), (3, 130), (21, 37), (48, 64), (45, 77)])
+def test_image_read_decodes_baseline_jpeg_as_libjpeg_does(tmp_path, size):
+    """rt_image_read stands in for image::open(path).into_rgb8() (texture.rs:89-93).  Files written by Pillow at every
+    chroma sampling the decoder takes, with and without restart markers and optimised tables, greyscale too: the
+    decode equals Pillow's (libjpeg's accurate IDCT and triangle upsampling) byte for byte."""
+    from PIL import Image
+    h, w = size
+    rng = np.random.default_rng(h * 1000 + w)
+    im = Image.fromarray(_smooth_noise(rng, h, w))
+    path = tmp_path / "t.jpg"
+    for sub in (0, 1, 2):
+        for q in (25, 75, 95):
+            for extra in ({}, {"restart_marker_blocks": 3}, {"restart_marker_rows": 1}, {"optimize": True}):
+                im.save(path, quality=q, subsampling=sub, **extra)
+                want = np.asarray(Image.open(path).convert("RGB"))
+                got = rtamd.read_image(path)
+                assert got.shape == want.shape and np.array_equal(got, want), (size, sub, q, extra)
+    im.convert("L").save(path, quality=80)
+    assert np.array_equal(rtamd.read_image(path), np.asarray(Image.open(path).convert("RGB")))
+
+
+def test_image_read_errors_and_ppm(tmp_path):
+    """A missing file is an I/O error, a file outside the decoder's formats unsupported (the reference panics on both,
+    texture.rs:91); binary PPM with comments in the header reads back as written."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    img = _smooth_noise(rng, 19, 23)
+    with pytest.raises(rtamd.RtError) as e:
+        rtamd.read_image(tmp_path / "nothing.jpg")
+    assert e.value.code == -6
+    Image.fromarray(img).save(tmp_path / "p.jpg", progressive=True)
+    Image.fromarray(img).save(tmp_path / "p.png")
+    (tmp_path / "junk.jpg").write_bytes(b"\xff\xd8\xff")
+    for name in ("p.jpg", "p.png", "junk.jpg"):
+        with pytest.raises(rtamd.RtError) as e:
+            rtamd.read_image(tmp_path / name)
+        assert e.value.code == -3, name
+    (tmp_path / "c.ppm").write_bytes(b"P6\n# a comment\n23 19\n# another\n255\n" + img.tobytes())
+    assert np.array_equal(rtamd.read_image(tmp_path / "c.ppm"), img)
+    rtamd.write_image(tmp_path / "w.ppm", img, "ppm")
+    assert np.array_equal(rtamd.read_image(tmp_path / "w.ppm"), img)
+    # a file cut inside its scan still decodes to the right size (missing data reads as zero bits, as libjpeg
+    # does); cut inside its headers it is refused
+    Image.fromarray(img).save(tmp_path / "whole.jpg")
+    raw = (tmp_path / "whole.jpg").read_bytes()
+    scan = raw.index(b"\xff\xda")
+    (tmp_path / "cut.jpg").write_bytes(raw[:scan + 60])
+    assert rtamd.read_image(tmp_path / "cut.jpg").shape == img.shape
+    (tmp_path / "cut2.jpg").write_bytes(raw[:scan - 20])
+    with pytest.raises(rtamd.RtError):
+        rtamd.read_image(tmp_path / "cut2.jpg")
+
+
+def test_mirror_image_texture_reads_a_jpeg(tmp_path):
+    """ImageTexture::new("earthmap.jpg") (main.rs:153,286) through the C++ mirror: the earth scene built from a JPEG
+    holds the texels libjpeg decodes.  With the reference's own file at hand, they are the committed fixture's."""
+    from PIL import Image
+    rng = np.random.default_rng(6)
+    Image.fromarray(_smooth_noise(rng, 64, 128)).save(tmp_path / "map.jpg", quality=85, subsampling=2)
+    got = rtamd.flattened_image("earth", earthmap=tmp_path / "map.jpg")
+    assert np.array_equal(got, np.asarray(Image.open(tmp_path / "map.jpg").convert("RGB")))
+    assert np.array_equal(rtamd.flattened_image("final_scene"), orc.earthmap())  # the PPM fixture, as before
+    ref_file = Path("/root/reference/raytracer-rs/earthmap.jpg")
+    if ref_file.exists():
+        assert np.array_equal(rtamd.read_image(ref_file), orc.earthmap())
+        assert np.array_equal(rtamd.flattened_image("earth", earthmap=ref_file), orc.earthmap())
+
+
 def test_accum_checkpoint_round_trip(tmp_path):
     rng = np.random.default_rng(2)
     acc = rng.uniform(0, 50, (9, 17, 3)).astype(np.float32)
