@@ -79,6 +79,8 @@ pub struct rt_scene_info {
     pub tree_seconds: f64,
     pub builder: u32,
     pub bvh_width: u32,
+    pub crown_nodes: u32,
+    pub reserved: u32,
 }
 #[repr(C)]
 #[derive(Default, Clone, Copy)]

@@ -167,6 +167,8 @@ typedef struct rt_scene_info {
     double tree_seconds;   /* of which: the world-level tree (build + upload of nodes and primitives) */
     uint32_t builder;      /* 0 host, 1 device */
     uint32_t bvh_width;    /* children per inner node the kernels walk: 2 or 4 */
+    uint32_t crown_nodes;  /* inner nodes the persistent trace kernel keeps in LDS (the whole tree of a small scene), 0 = none */
+    uint32_t reserved;
 } rt_scene_info;
 int rt_scene_get_info(rt_ctx* ctx, rt_scene_info* out);
 /* Inspection (tests, tools): copies the committed tree to host memory.  nodes: n_nodes records of 64 bytes

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -96,6 +97,7 @@ struct rt_ctx {
     int bvh_width = -1;  // children per inner node the kernels walk: 2, 4 (four-child form made at commit), -1 by tree size
     uint64_t wide_min_nodes = 1u << 16;  // bvh_width -1: trees of at least this many nodes (4 MiB, one XCD's L2) are walked four-wide
     DevBuf d_wide;
+    DevBuf d_crown;  // rtd::Scene::crown
     bool debug_live = false;
     bool settle_ahead = true;  // k_shade may settle the first medium's answer for the ray it makes (RTAMD_SETTLE_AHEAD=0: never)
     uint64_t tail_paths = 256u << 10;  // a batch with at most this many live paths is finished by one k_finish launch
@@ -426,6 +428,81 @@ struct ScopedTimer {
     }
 };
 
+// The crown of a committed tree (rtd::CROWN_BASE): up to max_nodes inner nodes, picked greedily by the area of their box
+// from the root downwards -- for rays spread evenly over the scene the chance of a visit goes with that area -- through
+// instance references into the instances' own trees as well.  The records are read back from the device one by one (a
+// few hundred small copies; the trees may have been built there) and written as Scene::crown describes.
+// words stays empty when the root is not an inner node.
+int build_crown(rt_ctx* c, bool wide, uint32_t root_ref, const std::vector<rtd::Group>& groups, uint32_t max_nodes, bool partial,
+                std::vector<uint32_t>& words, uint32_t& crown_root) {
+    words.clear();
+    crown_root = root_ref;
+    if (max_nodes == 0 || root_ref == rtd::REF_EMPTY || (root_ref >> 30) != rtd::REF_INNER) return RT_OK;
+    max_nodes = std::min(max_nodes, rtd::CROWN_MAX);
+    const size_t rec_words = wide ? sizeof(rtd::WideNode) / 4 : sizeof(rtd::Node) / 4;
+    const char* dev = (const char*)(wide ? c->d_wide.p : c->d_nodes.p);
+    struct Cand {
+        float area;
+        uint32_t node;
+        bool operator<(const Cand& o) const { return area < o.area; }
+    };
+    std::priority_queue<Cand> todo;
+    todo.push({INFINITY, root_ref & 0x3FFFFFFFu});
+    std::map<uint32_t, uint32_t> place;  // node index -> place in the crown
+    std::vector<uint32_t> recs;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    while (!todo.empty() && place.size() < max_nodes) {
+        const Cand cand = todo.top();
+        todo.pop();
+        if (place.count(cand.node)) continue;
+        place[cand.node] = (uint32_t)place.size();
+        recs.resize(recs.size() + rec_words);
+        uint32_t* rec = recs.data() + recs.size() - rec_words;
+        HIP_TRY(c, hipMemcpy(rec, dev + (size_t)cand.node * rec_words * 4, rec_words * 4, hipMemcpyDeviceToHost));
+        const int n_children = wide ? 4 : 2;
+        for (int k = 0; k < n_children; k++) {
+            const float* box = reinterpret_cast<const float*>(rec) + 6 * k;
+            uint32_t ref = rec[(wide ? 24 : 12) + k];
+            if (ref == rtd::REF_EMPTY) continue;
+            if ((ref >> 30) == rtd::REF_INSTANCE) {  // on into the instance's own tree
+                const uint32_t g = ref & 0x3FFFFFFFu;
+                if (g >= rtd::CROWN_INST_SLOTS || g >= groups.size()) continue;
+                ref = groups[g].root_ref;
+                if (ref == rtd::REF_EMPTY) continue;
+            }
+            if ((ref >> 30) != rtd::REF_INNER) continue;
+            const float dx = box[3] - box[0], dy = box[4] - box[1], dz = box[5] - box[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            todo.push({area == area ? area : 0.0f, ref & 0x3FFFFFFFu});
+        }
+    }
+    // Measured: a crown that holds only the top of a larger tree buys nothing (neighbouring lanes share the nodes near the
+    // root, and loads of the same address cost the texture path a quarter) while the large blocks cost a few per cent; with
+    // the whole tree in LDS the persistent walk of a few-hundred-sphere scene runs a fifth faster.
+    while (!todo.empty() && place.count(todo.top().node)) todo.pop();
+    if (!todo.empty() && !partial) return RT_OK;
+    words.assign(rtd::CROWN_INST_SLOTS, rtd::REF_EMPTY);
+    for (uint32_t g = 0; g < rtd::CROWN_INST_SLOTS && g < groups.size(); g++) {
+        const uint32_t r = groups[g].root_ref;
+        if (groups[g].kind == 1u && r != rtd::REF_EMPTY && (r >> 30) == rtd::REF_INNER && place.count(r & 0x3FFFFFFFu))
+            words[g] = rtd::CROWN_BASE + place[r & 0x3FFFFFFFu];
+    }
+    const size_t n = place.size();
+    for (size_t j = 0; j < n; j++) {
+        uint32_t* rec = recs.data() + j * rec_words;
+        for (int k = 0; k < (wide ? 4 : 2); k++) {
+            uint32_t& ref = rec[(wide ? 24 : 12) + k];
+            if (ref != rtd::REF_EMPTY && (ref >> 30) == rtd::REF_INNER) {
+                auto it = place.find(ref & 0x3FFFFFFFu);
+                if (it != place.end()) ref = rtd::CROWN_BASE + it->second;
+            }
+        }
+    }
+    words.insert(words.end(), recs.begin(), recs.end());
+    crown_root = rtd::CROWN_BASE + place[root_ref & 0x3FFFFFFFu];
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -506,6 +583,8 @@ int rt_ctx_create(int device, rt_ctx** out) {
     tn.settled_late_rounds = knob("RTAMD_SETTLED_LATE_ROUNDS", tn.settled_late_rounds, 1, 255);
     tn.settled_drain = knob("RTAMD_SETTLED_DRAIN", tn.settled_drain, 1, 64);
     tn.settled_oversub = knob("RTAMD_SETTLED_OVERSUB", tn.settled_oversub, 1, 64);
+    tn.crown_nodes = knob("RTAMD_CROWN_NODES", tn.crown_nodes, 0, 65535);
+    tn.crown_partial = knob("RTAMD_CROWN_PARTIAL", tn.crown_partial, 0, 1);
     *out = c;
     return RT_OK;
 }
@@ -517,7 +596,7 @@ void rt_ctx_destroy(rt_ctx* c) {
     (void)rt_comm_destroy(c);
     DevBuf* xbufs[] = {&c->d_tile_off, &c->d_packed, &c->d_gathered, &c->d_xin, &c->d_xout};
     for (DevBuf* b : xbufs) b->release();
-    DevBuf* bufs[] = {&c->d_prims, &c->d_moving, &c->d_nodes, &c->d_wide, &c->d_groups, &c->d_mats, &c->d_texs, &c->d_perlin,
+    DevBuf* bufs[] = {&c->d_prims, &c->d_moving, &c->d_nodes, &c->d_wide, &c->d_crown, &c->d_groups, &c->d_mats, &c->d_texs, &c->d_perlin,
                       &c->d_images, &c->d_media, &c->d_hits, &c->d_radiance, &c->d_counts, &c->d_rays, &c->d_overflow, &c->d_pixels,
                       &c->d_accum};
     for (DevBuf* b : bufs) b->release();
@@ -1086,6 +1165,16 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     }
     c->stack_entries = (int)(flat_ok ? 1u : need);
     c->has_groups = ng > 0;
+    std::vector<uint32_t> crown_words;
+    uint32_t crown_root = top_r.root_ref;
+    {
+        const uint32_t cap = rtk::crown_capacity(c->tune, ng > 0, wide, need);
+        const bool worth = c->tune.crown_partial || n_nodes_total <= cap;  // (instances beyond CROWN_INST_SLOTS aside, it all fits)
+        if (!flat_ok && !nested && n_nodes_total > 0 && cap > 0 && worth &&
+            (rc = build_crown(c, wide, top_r.root_ref, dgroups, cap, c->tune.crown_partial != 0, crown_words, crown_root)))
+            return rc;
+    }
+    if ((rc = upload(c, c->d_crown, crown_words.data(), crown_words.size() * sizeof(uint32_t)))) return rc;
 
     // upload
     if ((rc = upload(c, c->d_groups, dgroups.data(), dgroups.size() * sizeof(rtd::Group)))) return rc;
@@ -1173,6 +1262,9 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     S.near0_n = near0_known ? (uint32_t)near0.size() : rtd::NEAR_NONE;
     S.near0_ball = near0_ball ? 1u : 0u;
     S.settle_fast = settle_fast ? 1u : 0u;
+    S.crown = crown_words.empty() ? nullptr : (const uint32_t*)c->d_crown.p;
+    S.crown_n = crown_words.empty() ? 0u : (uint32_t)((crown_words.size() - rtd::CROWN_INST_SLOTS) / (wide ? 32 : 16));
+    S.crown_root = crown_root;
     S.flat = flat_ok ? 1u : 0u;
     S.nested = nested ? 1u : 0u;
     S.stack_cap = flat_ok ? 1u : need;  // flat scenes never push
@@ -1189,6 +1281,8 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     c->info.n_nodes = n_nodes_total;
     c->info.builder = device_build ? 1u : 0u;
     c->info.bvh_width = wide ? 4u : 2u;
+    c->info.crown_nodes = S.crown_n;
+    c->info.reserved = 0;
     c->info.n_groups = ng;
     c->info.n_media = n_media;
     c->info.max_depth = need;

@@ -604,14 +604,45 @@ DEV void near_first(float& ka, uint32_t& ra, float& kb, uint32_t& rb) {
     ka = k;
     ra = r;
 }
+// The crown in LDS (kernels compiled with CROWN: the trace kernel puts it at the start of its dynamic LDS, the instance
+// table first): a node fetched from there costs no address cycles of the texture path -- a wave's scattered 16-byte loads
+// take one cycle per lane and instruction there, which is what bounds the walk -- and a fraction of the latency.
+// (The reads are typed as LDS reads, address space 3: through plain pointers the compiler folds "this node from LDS, that
+// one from memory" into ONE flat load of a selected address, and flat loads take the texture path whatever they hit.)
+typedef float crown_v4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const crown_v4 crown_lds_v4;
+typedef __attribute__((address_space(3))) const uint32_t crown_lds_u32;
+DEV crown_lds_u32* crown_words() {
+    extern __shared__ __attribute__((aligned(16))) uint32_t crown_lds_base[];
+    return (crown_lds_u32*)crown_lds_base;
+}
+// 16-byte piece k of crown record `index` of `pieces` pieces
+DEV float4 crown_piece(uint32_t index, uint32_t pieces, uint32_t k) {
+    crown_lds_v4* p = (crown_lds_v4*)(crown_words() + CROWN_INST_SLOTS) + index * pieces + k;
+    const crown_v4 v = *p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 // The same walk over four-child nodes: one 128-byte fetch decides about four boxes, which halves the chain of
 // dependent fetches per ray.  The children that are hit are entered nearest first; the others wait on the stack,
 // the farthest at the bottom.  Every valid tree gives the same closest hit, so the result equals the binary walk's.
-template <int STRIDE, bool COUNT>
+template <int STRIDE, bool COUNT, bool CROWN = false>
 DEV void inner_step_wide(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt) {
     {
-        const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
+        float4 q0, q1, q2, q3, q4, q5, q6;
+        const uint32_t ci = w.cur - CROWN_BASE;
+        if (CROWN && ci <= CROWN_MAX) {
+            q0 = crown_piece(ci, 8u, 0u), q1 = crown_piece(ci, 8u, 1u), q2 = crown_piece(ci, 8u, 2u), q3 = crown_piece(ci, 8u, 3u);
+            q4 = crown_piece(ci, 8u, 4u), q5 = crown_piece(ci, 8u, 5u), q6 = crown_piece(ci, 8u, 6u);
+        } else {
+            const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
+            q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
+#ifdef RT_EXTRA_LOAD  // timing experiment: one more 16-byte load per node (the record's unused tail), its value consumed
+            {
+                const float4 q7 = np[7];
+                asm volatile("" ::"v"(q7.x), "v"(q7.y), "v"(q7.z), "v"(q7.w));
+            }
+#endif
+        }
         if (COUNT) {
             cnt->nodes++;
             if (first_active_lane()) cnt->inner_waves++;
@@ -658,14 +689,28 @@ DEV void inner_step_wide(const Scene& S, Walk& w, float tmin, const Stack& stk, 
 }
 // WIDTH: 2 / 4 = the kernel is compiled for the binary / the four-child walk only (the persistent trace kernel: the
 // binary walk alone needs 64 instead of 72 registers, one more resident wave per SIMD); 0 = whichever the scene holds.
-template <int STRIDE, bool COUNT, int WIDTH = 0>
+template <int STRIDE, bool COUNT, int WIDTH = 0, bool CROWN = false>
 DEV void inner_step(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt) {
     if (WIDTH == 4 || (WIDTH == 0 && S.wide)) {  // (the same in every lane)
-        inner_step_wide<STRIDE, COUNT>(S, w, tmin, stk, overflow_flag, cnt);
+        inner_step_wide<STRIDE, COUNT, CROWN>(S, w, tmin, stk, overflow_flag, cnt);
         return;
     }
-    const float4* np = reinterpret_cast<const float4*>(S.nodes + w.cur);
-    float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    float4 q0, q1, q2, q3;
+    const uint32_t ci = w.cur - CROWN_BASE;
+    if (CROWN && ci <= CROWN_MAX) {
+        q0 = crown_piece(ci, 4u, 0u), q1 = crown_piece(ci, 4u, 1u), q2 = crown_piece(ci, 4u, 2u), q3 = crown_piece(ci, 4u, 3u);
+    } else {
+        const float4* np = reinterpret_cast<const float4*>(S.nodes + w.cur);
+        q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+#ifdef RT_EXTRA_LOAD  // timing experiment: one more 16-byte load per node (its first piece again), its value consumed
+        {
+            const float4* again = np;
+            asm volatile("" : "+v"(again));
+            const float4 q7 = again[0];
+            asm volatile("" ::"v"(q7.x), "v"(q7.y), "v"(q7.z), "v"(q7.w));
+        }
+#endif
+    }
     if (COUNT) {
         cnt->nodes++;
         if (first_active_lane()) cnt->inner_waves++;
@@ -707,13 +752,15 @@ DEV void inner_step(const Scene& S, Walk& w, float tmin, const Stack& stk, uint3
     }
 }
 // Walks inner nodes only (at most max_steps of them), until cur is a leaf, an instance, a sentinel or empty.
-template <int STRIDE, bool COUNT, int WIDTH = 0>
+template <int STRIDE, bool COUNT, int WIDTH = 0, bool CROWN = false>
 DEV void walk_inner(const Scene& S, Walk& w, float tmin, const Stack& stk, uint32_t* overflow_flag, TraceCount* cnt, int max_steps) {
-    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++) inner_step<STRIDE, COUNT, WIDTH>(S, w, tmin, stk, overflow_flag, cnt);
+    for (int step = 0; step < max_steps && (w.cur >> 30) == REF_INNER; step++)
+        inner_step<STRIDE, COUNT, WIDTH, CROWN>(S, w, tmin, stk, overflow_flag, cnt);
 }
 // One non-inner step: tests a leaf's primitives, enters an instance or leaves it, then takes the next entry
 // from the stack.  No-op when cur is an inner node or empty.
-template <int STRIDE, int GROUPS, bool COUNT>
+// CROWN: an instance whose root is in the crown is entered there.
+template <int STRIDE, int GROUPS, bool COUNT, bool CROWN = false>
 DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin, const Stack& stk, uint32_t* overflow_flag,
                    TraceCount* cnt) {
     const uint32_t type = w.cur >> 30;
@@ -738,6 +785,10 @@ DEV void walk_leaf(const Scene& S, Walk& w, f3 wo, f3 wd, float time, float tmin
         uint32_t g = w.cur & 0x3FFFFFFFu;
         const Group& G = S.groups[g];
         uint32_t root = G.root_ref;
+        if (CROWN && g < CROWN_INST_SLOTS) {
+            const uint32_t in_crown = crown_words()[g];
+            root = in_crown != REF_EMPTY ? in_crown : root;
+        }
         w.cur = REF_EMPTY;
         if (root != REF_EMPTY) {
             if (w.sp < (int)S.stack_cap) {

@@ -22,6 +22,14 @@ constexpr uint32_t MAX_PRIMS = 1u << 26;
 inline uint32_t make_ref(uint32_t type, uint32_t index) { return (type << 30) | index; }
 inline uint32_t make_prim_ref(uint32_t first, uint32_t count) { return (REF_PRIMS << 30) | ((count - 1u) << 26) | first; }
 
+// The crown: copies of the inner nodes a ray is most likely to visit (the top of the world's tree and of the instances'
+// trees, picked at commit by box area), which the persistent trace kernel keeps in LDS.  Inside those copies a child
+// that is itself in the crown is referred to as an inner node with index CROWN_BASE + its place in the crown: no tree
+// has that many nodes, so the walk tells the two apart with one compare.  Only walks that start at Scene::crown_root
+// ever meet such a reference.
+constexpr uint32_t CROWN_BASE = 0x3FFF0000u, CROWN_MAX = 0xFFFFu;
+constexpr uint32_t CROWN_INST_SLOTS = 64u;  // instance groups below this index can have their root in the crown
+
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
 constexpr uint32_t HIT_MEDIUM_BIT = 0x80000000u;  // hit.prim = HIT_MEDIUM_BIT | group index
 constexpr uint32_t MEDIUM_KEY_BASE = 0x40000000u; // tie key of the k-th medium
@@ -153,6 +161,11 @@ struct Scene {
     // != 0 (needs near0_ball): every medium (at most 4) is one resting sphere in world space with a plain-colour phase
     // material, and the near list holds at most one primitive, a resting sphere: k_settled may take its specialised step
     uint32_t settle_fast;
+    // The crown (see CROWN_BASE), or crown_n == 0.  Device memory: CROWN_INST_SLOTS words (word g: the crown reference of
+    // instance group g's root, REF_EMPTY when it is not in the crown), then crown_n records (Node, or WideNode when wide is
+    // set) whose child references point into the crown where they can.  crown_root: the root's crown reference.
+    const uint32_t* crown;
+    uint32_t crown_n, crown_root;
 };
 constexpr uint32_t NEAR_NONE = 0xFFFFFFFFu;
 

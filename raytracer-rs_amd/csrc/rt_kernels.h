@@ -81,6 +81,8 @@ struct Tuning {
     int settled_slow_min = 4;       // RTAMD_SETTLED_SLOW_MIN: lanes of a wave of k_settled that must wait for the general step before it runs
     int settled_fast = 1;           // RTAMD_SETTLED_FAST=0: never the step specialised for sphere-shaped media (Scene::settle_fast)
     int settled_oversub = 1;        // RTAMD_SETTLED_OVERSUB: grid of k_settled, in rounds of resident blocks
+    int crown_nodes = 4096;         // RTAMD_CROWN_NODES: most inner nodes k_trace may keep in LDS (0: none); the LDS left beside the stacks bounds it too
+    int crown_partial = 0;          // RTAMD_CROWN_PARTIAL: 1 = keep the top of a tree that does not fit as a whole (measured: no gain)
 };
 
 struct TraceCfg {
@@ -110,6 +112,9 @@ hipError_t launch_shade(hipStream_t s, const Tuning& tn, const rtd::Scene& scene
                         unsigned long long* stats, bool may_settle);
 // true when launch_shade(..., may_settle = true) queues settled paths for this scene, i.e. launch_settled has to follow
 bool scene_settles(const rtd::Scene& scene);
+// Inner nodes (64-byte records, or 128-byte ones of the four-child form) that fit into the LDS of a k_trace block beside its
+// traversal stacks and world rays, with two blocks of 1024 threads per compute unit.
+uint32_t crown_capacity(const Tuning& tn, bool has_groups, bool wide, uint32_t stack_cap);
 // The paths launch `bounce - 1` of k_shade queued at the far end of `in`: each is followed in registers, bounce after
 // bounce, for as long as its next hit can be settled without the tree; a path that leaves is appended to the front of `out`.
 hipError_t launch_settled(hipStream_t s, const Tuning& tn, const rtd::Scene& scene, const RenderConst& rc, PathState in, PathState out,

@@ -503,13 +503,27 @@ __global__ __launch_bounds__(rtk::BLOCK) void k_raygen(rtk::RenderConst rc, rtk:
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 7
 #endif
+#ifndef CROWN_BLOCK
+#define CROWN_BLOCK 1024  // threads per block of the trace kernel that keeps the crown in LDS
+#endif
 // WIDTH: children per inner node the walk is compiled for (2 or 4; a launch picks the one the scene holds)
-template <int GROUPS, bool COUNT, bool FLAT, int WIDTH>
-__global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRACE_WAVES))) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
+// TB: threads per block.  CROWN: the block keeps the scene's crown (Scene::crown, rtd::CROWN_BASE) at the start of its LDS and
+// is launched with S.root_ref = S.crown_root; blocks are large then (one copy of the crown serves 16 waves).
+template <int GROUPS, bool COUNT, bool FLAT, int WIDTH, int TB = rtk::BLOCK, bool CROWN = false>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(CROWN ? 8 : TRACE_WAVES))) void k_trace(Scene S, rtk::PathState in, rtk::Queues q, uint32_t bounce,
                                                        float4* __restrict__ hits, unsigned long long* stats,
                                                        uint32_t* overflow_flag, uint32_t REFILL, int INNER_STEPS, uint32_t lds_entries,
                                                        uint32_t* spill) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];  // lds_entries entries per lane, [entry][lane]; deeper ones spill
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    // the crown (instance table, then the records), then lds_entries stack entries per lane, [entry][lane]; deeper ones spill
+    const uint32_t crown_words_n = CROWN ? CROWN_INST_SLOTS + S.crown_n * (WIDTH == 4 ? 32u : 16u) : 0u;
+    uint32_t* stack = lds_all + crown_words_n;
+    if (CROWN) {
+        const uint4* src = reinterpret_cast<const uint4*>(S.crown);
+        uint4* dst = reinterpret_cast<uint4*>(lds_all);
+        for (uint32_t i = threadIdx.x; i < crown_words_n / 4u; i += TB) dst[i] = src[i];
+        __syncthreads();
+    }
     const uint32_t shard = blockIdx.x % rtk::NSHARD, j0 = blockIdx.x / rtk::NSHARD, stride = gridDim.x / rtk::NSHARD;
     const uint32_t n = q.counts[(bounce % 3u) * rtk::NSHARD + shard];
     const uint32_t shard_base = shard * q.cap_shard;
@@ -518,10 +532,10 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
         if (n) atomicAdd(stats, (unsigned long long)n);
     }
     // blockIdx.x * BLOCK + threadIdx.x is this thread's column of the spill area (gridDim.x * BLOCK columns)
-    const Stack stk{stack + threadIdx.x, lds_entries, spill + (size_t)blockIdx.x * rtk::BLOCK + threadIdx.x, gridDim.x * (uint32_t)rtk::BLOCK};
+    const Stack stk{stack + threadIdx.x, lds_entries, spill + (size_t)blockIdx.x * TB + threadIdx.x, gridDim.x * (uint32_t)TB};
     TraceCount tc{0u, 0u, 0u, 0u, 0u};
     if (FLAT) {  // no tree, no divergence between rays: plain strided loop
-        for (uint32_t i = j0 * rtk::BLOCK + threadIdx.x; i < n; i += stride * rtk::BLOCK) {
+        for (uint32_t i = j0 * TB + threadIdx.x; i < n; i += stride * TB) {
             const uint32_t at = shard_base + i;
             const float4 ot = in.o_time[at], ds = in.d_slot[at];
             Hit h;
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
     // rays differ several-fold in how many nodes they visit, and a wave that waits for its longest ray runs at
     // ~27% lane use.  So a lane whose ray is finished does not wait for the tile: once REFILL lanes are free
     // (or none is busy), they take the next rays of the run.  Surfaces only: the media are applied by k_shade.
-    const uint32_t nw = stride * (rtk::BLOCK / 64u), wi = j0 * (rtk::BLOCK / 64u) + (threadIdx.x >> 6);
+    const uint32_t nw = stride * (TB / 64u), wi = j0 * (TB / 64u) + (threadIdx.x >> 6);
     const uint32_t per = (((n + nw - 1u) / nw) + 63u) & ~63u;
     uint32_t next = __builtin_amdgcn_readfirstlane(wi * per);
     const uint32_t end = __builtin_amdgcn_readfirstlane(next + per < n ? next + per : n);
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
     f3 wo{0, 0, 0}, wd{0, 0, 0};
     // With instances the world ray is needed again wherever the walk enters or leaves one.  It waits in this lane's own
     // LDS words behind the stacks ([component][lane]) rather than in six registers: those cost a resident wave per SIMD.
-    float* world_ray = reinterpret_cast<float*>(stack + (size_t)lds_entries * rtk::BLOCK) + threadIdx.x;
+    float* world_ray = reinterpret_cast<float*>(stack + (size_t)lds_entries * TB) + threadIdx.x;
     float time = 0.0f;
     Walk w;
     walk_begin(S, w, wo, wd, INF_F);
@@ -570,12 +584,12 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
                 wd = mk3(ds.x, ds.y, ds.z);
                 time = ot.w;
                 if (GROUPS) {
-                    world_ray[0 * rtk::BLOCK] = wo.x;
-                    world_ray[1 * rtk::BLOCK] = wo.y;
-                    world_ray[2 * rtk::BLOCK] = wo.z;
-                    world_ray[3 * rtk::BLOCK] = wd.x;
-                    world_ray[4 * rtk::BLOCK] = wd.y;
-                    world_ray[5 * rtk::BLOCK] = wd.z;
+                    world_ray[0 * TB] = wo.x;
+                    world_ray[1 * TB] = wo.y;
+                    world_ray[2 * TB] = wo.z;
+                    world_ray[3 * TB] = wd.x;
+                    world_ray[4 * TB] = wd.y;
+                    world_ray[5 * TB] = wd.z;
                 }
                 walk_begin(S, w, wo, wd, INF_F);
                 have = true;
@@ -590,20 +604,20 @@ __global__ __launch_bounds__(rtk::BLOCK) __attribute__((amdgpu_waves_per_eu(TRAC
             if (have) busy_lanes++;
         }
         if (have) {
-            walk_inner<rtk::BLOCK, COUNT, WIDTH>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
+            walk_inner<TB, COUNT, WIDTH, CROWN>(S, w, 0.005f, stk, overflow_flag, &tc, INNER_STEPS);
             // (without instances the walk never leaves world space: its own copy of the ray is the world ray, and keeping
             // a second one would cost the kernel a resident wave per SIMD)
             if (GROUPS) {
                 const uint32_t type = w.cur >> 30;
                 if (w.cur != REF_EMPTY && type != REF_INNER && type != REF_PRIMS) {  // instance or sentinel
-                    const f3 lo = mk3(world_ray[0 * rtk::BLOCK], world_ray[1 * rtk::BLOCK], world_ray[2 * rtk::BLOCK]);
-                    const f3 ld = mk3(world_ray[3 * rtk::BLOCK], world_ray[4 * rtk::BLOCK], world_ray[5 * rtk::BLOCK]);
-                    walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, lo, ld, time, 0.005f, stk, overflow_flag, &tc);
+                    const f3 lo = mk3(world_ray[0 * TB], world_ray[1 * TB], world_ray[2 * TB]);
+                    const f3 ld = mk3(world_ray[3 * TB], world_ray[4 * TB], world_ray[5 * TB]);
+                    walk_leaf<TB, GROUPS, COUNT, CROWN>(S, w, lo, ld, time, 0.005f, stk, overflow_flag, &tc);
                 } else {
-                    walk_leaf<rtk::BLOCK, 0, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
+                    walk_leaf<TB, 0, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
                 }
             } else {
-                walk_leaf<rtk::BLOCK, GROUPS, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
+                walk_leaf<TB, GROUPS, COUNT>(S, w, w.o, w.d, time, 0.005f, stk, overflow_flag, &tc);
             }
             if (walk_done(w)) {
                 hits[idx] = make_float4(w.best.t, __uint_as_float(w.best.prim), __int_as_float(w.best.grp), __uint_as_float(w.best.key));
@@ -1234,7 +1248,7 @@ inline int grid_flat(unsigned long long n) {
 // split pipeline balances inside each wave instead and wants long runs per wave: 2.
 // (the factors come from rtk::Tuning: oversub, trace_oversub)
 // Blocks of kernel `fn` that are resident at once on the current device.
-uint32_t resident_blocks(const void* fn, size_t smem) {
+uint32_t resident_blocks(const void* fn, size_t smem, int threads = rtk::BLOCK) {
     static std::mutex mu;
     static std::map<std::tuple<const void*, int, size_t>, uint32_t> cache;
     int dev = 0;
@@ -1244,7 +1258,7 @@ uint32_t resident_blocks(const void* fn, size_t smem) {
     if (it != cache.end()) return it->second;
     int per_cu = 0, cus = 0;
     uint32_t n = 1024;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, rtk::BLOCK, smem) == hipSuccess &&
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, smem) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
         n = (uint32_t)(per_cu * cus);
     else
@@ -1252,8 +1266,8 @@ uint32_t resident_blocks(const void* fn, size_t smem) {
     cache[std::make_tuple(fn, dev, smem)] = n;
     return n;
 }
-inline int grid_sharded(uint32_t blocks_per_shard, const void* fn, int oversub, size_t smem = 0) {
-    uint32_t lim = std::max<uint32_t>(1u, resident_blocks(fn, smem) * (uint32_t)oversub / rtk::NSHARD);
+inline int grid_sharded(uint32_t blocks_per_shard, const void* fn, int oversub, size_t smem = 0, int threads = rtk::BLOCK) {
+    uint32_t lim = std::max<uint32_t>(1u, resident_blocks(fn, smem, threads) * (uint32_t)oversub / rtk::NSHARD);
     if (lim > (uint32_t)rtk::MAX_BLOCKS_PER_SHARD) lim = rtk::MAX_BLOCKS_PER_SHARD;
     if (blocks_per_shard < 1) blocks_per_shard = 1;
     if (blocks_per_shard > lim) blocks_per_shard = lim;
@@ -1308,17 +1322,81 @@ hipError_t launch_raygen(hipStream_t s, const Tuning& tn, const RenderConst& rc,
 uint32_t trace_lds_entries(const Tuning& tn, const Scene& scene) {
     return std::min<uint32_t>(std::max(1u, scene.stack_cap), (uint32_t)std::max(1, tn.stack_lds));
 }
+// Makes sure `bytes` of spill columns exist.
+static hipError_t ensure_spill(SpillArea& spill, size_t need) {
+    if (need <= spill.bytes) return hipSuccess;
+    if (spill.p) (void)hipFree(spill.p);
+    spill.p = nullptr;
+    spill.bytes = 0;
+    hipError_t e = hipMalloc(&spill.p, need);
+    if (e == hipSuccess) spill.bytes = need;
+    return e;
+}
+// Dynamic LDS beyond 64 KiB has to be asked for once per kernel.
+static hipError_t allow_lds(const void* fn, size_t smem) {
+    static std::mutex mu;
+    static std::map<const void*, size_t> allowed;
+    if (smem <= 64u * 1024u) return hipSuccess;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = allowed.find(fn);
+    if (it != allowed.end() && it->second >= smem) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) allowed[fn] = smem;
+    return e;
+}
+uint32_t crown_capacity(const Tuning& tn, bool has_groups, bool wide, uint32_t stack_cap) {
+    if (tn.crown_nodes <= 0) return 0u;
+    const size_t lds_entries = std::min<uint32_t>(std::max(1u, stack_cap), (uint32_t)std::max(1, tn.stack_lds));
+    const size_t per_block = 80u * 1024u;  // two blocks per compute unit (160 KiB)
+    const size_t fixed = CROWN_INST_SLOTS * sizeof(uint32_t) + lds_entries * CROWN_BLOCK * sizeof(uint32_t) +
+                         (has_groups ? (size_t)CROWN_BLOCK * 6 * sizeof(float) : 0);
+    if (fixed >= per_block) return 0u;
+    const size_t fit = (per_block - fixed) / (wide ? sizeof(WideNode) : sizeof(Node));
+    return (uint32_t)std::min<size_t>(std::min<size_t>(fit, (size_t)tn.crown_nodes), CROWN_MAX);
+}
+// Whether launch_trace walks with the crown in LDS (see rtd::CROWN_BASE).
+bool trace_uses_crown(const Tuning& tn, const TraceCfg& cfg, const Scene& scene) {
+    return tn.crown_nodes > 0 && scene.crown_n > 0u && !scene.flat && !cfg.nested && !cfg.count_visits;
+}
 hipError_t launch_trace(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, const Scene& scene, PathState in, Queues q, uint32_t bounce,
                         uint32_t blocks_per_shard, float4* hits, unsigned long long* stats, uint32_t* overflow_flag,
                         SpillArea& spill) {
-    const dim3 block(BLOCK);
     const uint32_t lds_entries = trace_lds_entries(tn, scene);
-    // stacks, then (scenes with instances) each lane's world ray
-    const size_t smem = (size_t)lds_entries * BLOCK * sizeof(uint32_t) + (cfg.has_groups ? (size_t)BLOCK * 6 * sizeof(float) : 0);
     const uint32_t deep = std::max(1u, scene.stack_cap) - lds_entries;
     // A wave refills its free lanes from its own run of the queue, so a run of one tile gives it nothing to refill
     // from.  When few rays are queued, launch fewer blocks rather than shorter runs: at least min_run rays per wave.
     const int min_run = std::max(8, tn.trace_min_run);
+    if (trace_uses_crown(tn, cfg, scene)) {
+        // Large blocks, so that one copy of the crown serves many waves: [crown][stacks][world rays]
+        constexpr int TB = CROWN_BLOCK;
+        const size_t smem = (size_t)(CROWN_INST_SLOTS + scene.crown_n * (scene.wide ? 32u : 16u)) * sizeof(uint32_t) +
+                            (size_t)lds_entries * TB * sizeof(uint32_t) + (cfg.has_groups ? (size_t)TB * 6 * sizeof(float) : 0);
+        Scene sc = scene;
+        sc.root_ref = scene.crown_root;
+        const uint32_t bps = std::max(1u, (blocks_per_shard * BLOCK + (TB / 64) * min_run - 1) / ((TB / 64) * min_run));
+#define RT_TRACE_CROWN(G, W)                                                                                                          \
+    do {                                                                                                                              \
+        const void* fn = (const void*)&k_trace<G, false, false, W, TB, true>;                                                         \
+        hipError_t e = allow_lds(fn, smem);                                                                                           \
+        if (e != hipSuccess) return e;                                                                                                \
+        const int grid = grid_sharded(bps, fn, tn.trace_oversub, smem, TB);                                                           \
+        if ((e = ensure_spill(spill, (size_t)deep * grid * TB * sizeof(uint32_t))) != hipSuccess) return e;                           \
+        hipLaunchKernelGGL((k_trace<G, false, false, W, TB, true>), dim3(grid), dim3(TB), smem, s, sc, in, q, bounce, hits, stats,    \
+                           overflow_flag, (uint32_t)tn.refill, tn.inner_steps, lds_entries, (uint32_t*)spill.p);                      \
+    } while (0)
+        if (cfg.has_groups) {
+            if (scene.wide) RT_TRACE_CROWN(1, 4);
+            else RT_TRACE_CROWN(1, 2);
+        } else {
+            if (scene.wide) RT_TRACE_CROWN(0, 4);
+            else RT_TRACE_CROWN(0, 2);
+        }
+#undef RT_TRACE_CROWN
+        return hipGetLastError();
+    }
+    const dim3 block(BLOCK);
+    // stacks, then (scenes with instances) each lane's world ray
+    const size_t smem = (size_t)lds_entries * BLOCK * sizeof(uint32_t) + (cfg.has_groups ? (size_t)BLOCK * 6 * sizeof(float) : 0);
     blocks_per_shard = std::max(1u, (blocks_per_shard * BLOCK + (BLOCK / 64) * min_run - 1) / ((BLOCK / 64) * min_run));
 #define RT_CALL(G, C, F)                                       \
     do {                                                       \
@@ -1328,15 +1406,8 @@ hipError_t launch_trace(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, co
 #define RT_TRACE(G, C, F, W)                                                                                                     \
     do {                                                                                                                         \
         const int grid = grid_sharded(blocks_per_shard, (const void*)&k_trace<G, C, F, W>, tn.trace_oversub, smem);      \
-        const size_t need = (size_t)deep * grid * BLOCK * sizeof(uint32_t);                                                      \
-        if (need > spill.bytes) {                                                                                                \
-            if (spill.p) (void)hipFree(spill.p);                                                                                 \
-            spill.p = nullptr;                                                                                                   \
-            spill.bytes = 0;                                                                                                     \
-            hipError_t e = hipMalloc(&spill.p, need);                                                                            \
-            if (e != hipSuccess) return e;                                                                                       \
-            spill.bytes = need;                                                                                                  \
-        }                                                                                                                        \
+        hipError_t e = ensure_spill(spill, (size_t)deep * grid * BLOCK * sizeof(uint32_t));                                      \
+        if (e != hipSuccess) return e;                                                                                           \
         hipLaunchKernelGGL((k_trace<G, C, F, W>), dim3(grid), block, smem, s, scene, in, q, bounce, hits, stats, overflow_flag,  \
                            (uint32_t)tn.refill, tn.inner_steps, lds_entries,                                                     \
                            (uint32_t*)spill.p);                                                                                  \

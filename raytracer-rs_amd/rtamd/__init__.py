@@ -77,7 +77,7 @@ class rt_scene_info(C.Structure):
     _fields_ = [("n_prims", C.c_uint64), ("n_nodes", C.c_uint64), ("n_groups", C.c_uint64), ("n_media", C.c_uint64),
                 ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32), ("device_bytes", C.c_uint64),
                 ("build_seconds", C.c_double), ("tree_seconds", C.c_double), ("builder", C.c_uint32),
-                ("bvh_width", C.c_uint32)]
+                ("bvh_width", C.c_uint32), ("crown_nodes", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -559,6 +559,48 @@ def test_settling_the_first_medium_ahead_changes_no_bit(name, monkeypatch):
         assert rays == out[0][1] and np.array_equal(img, out[0][0])
 
 
+@pytest.mark.parametrize("name, env, width, fits", [
+    ("random_world", {}, 2, True),                                       # a few hundred nodes: the whole tree
+    ("random_world", {"RTAMD_CROWN_PARTIAL": "1", "RTAMD_CROWN_NODES": "100"}, 2, False),
+    ("random_world", {"RTAMD_CROWN_PARTIAL": "1"}, 4, False),            # four-child records, the top of the tree
+    ("final_scene", {"RTAMD_CROWN_PARTIAL": "1"}, 2, False),             # world tree + the top of the instance's own tree
+    ("final_scene", {"RTAMD_CROWN_PARTIAL": "1", "RTAMD_CROWN_NODES": "40"}, 4, False),
+    ("cornell_smoke", {"RTAMD_FLAT_MAX": "0"}, 2, True),                 # instances and media, traced through trees: all of it
+])
+def test_tree_nodes_kept_in_lds_change_no_bit(name, env, width, fits, monkeypatch):
+    """The persistent trace kernel may keep inner nodes in LDS (by default: the whole tree of a scene where that fits, which is
+    what pays; for this test also the top of trees that do not fit): copies of the same records, child references inside the
+    copies pointing at copies, instance roots entered through a table.  Same boxes in the same order, so image and ray count
+    must be those of the walk that reads every node from memory."""
+    w, h, spp = 160, 120, 12
+    out = []
+    for case in (dict(RTAMD_CROWN_NODES="0"), env):
+        for k in ("RTAMD_CROWN_NODES", "RTAMD_CROWN_PARTIAL", "RTAMD_FLAT_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        if "RTAMD_FLAT_MAX" in env:
+            monkeypatch.setenv("RTAMD_FLAT_MAX", env["RTAMD_FLAT_MAX"])
+        for k, v in case.items():
+            monkeypatch.setenv(k, v)  # (a context reads its knobs when it is created)
+        ctx = rtamd.Context(0)
+        ctx.set_bvh_width(width)
+        ctx.set_tail_paths(0)
+        ctx.load_scene(name, seed=3)
+        info = ctx.info()
+        if case is env:
+            assert info["bvh_width"] == width
+            assert (info["crown_nodes"] == info["n_nodes"]) if fits else (0 < info["crown_nodes"] < info["n_nodes"])
+        else:
+            assert info["crown_nodes"] == 0
+        cam = ctx.preset_camera(w / h)
+        for pipe in (0, 2):  # the trace kernel from the camera rays on / after a fused first bounce
+            ctx.set_pipeline(pipe)
+            img, st = ctx.render(w, h, cam, spp, seed=9)
+            out.append((img, st["rays"]))
+        ctx.close()
+    for img, rays in out[1:]:
+        assert rays == out[0][1] and np.array_equal(img, out[0][0])
+
+
 @pytest.mark.parametrize("glass, n_media", [(False, 1), (False, 3), (True, 2), (True, 4)])
 def test_settled_paths_in_raw_scenes_of_sphere_shaped_media(glass, n_media, monkeypatch):
     """The step of k_settled that is specialised for sphere-shaped media of plain colour, on scenes sent through the raw ABI:
@@ -833,6 +875,6 @@ def test_bench_default_workload_walks_the_tree():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
     assert d["config"]["workload"] == "final_scene" and d["config"]["frames"] == ["final_scene"] and d["config"]["max_depth"] == 50
     roof = d["roofline"]
-    assert roof["trace_ms_per_step"] > 0 and roof["kernel"] in ("k_trace", "k_shade", "k_bounce") and 0 < roof["frac"] <= 1.0
+    assert roof["trace_ms_per_step"] > 0 and roof["kernel"] in ("k_trace", "k_shade", "k_bounce", "k_settled") and 0 < roof["frac"] <= 1.0
     assert roof["nodes_per_ray"][0] > 5
     assert 3.0 < d["config"]["rays_per_step"] / d["config"]["paths_per_step"] < 7.0
