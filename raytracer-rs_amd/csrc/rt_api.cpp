@@ -585,6 +585,7 @@ int rt_ctx_create(int device, rt_ctx** out) {
     tn.settled_oversub = knob("RTAMD_SETTLED_OVERSUB", tn.settled_oversub, 1, 64);
     tn.crown_nodes = knob("RTAMD_CROWN_NODES", tn.crown_nodes, 0, 65535);
     tn.crown_partial = knob("RTAMD_CROWN_PARTIAL", tn.crown_partial, 0, 1);
+    tn.crown_min_blocks = knob("RTAMD_CROWN_MIN_BLOCKS", tn.crown_min_blocks, 0, 1 << 20);
     *out = c;
     return RT_OK;
 }

@@ -82,6 +82,7 @@ struct Tuning {
     int settled_fast = 1;           // RTAMD_SETTLED_FAST=0: never the step specialised for sphere-shaped media (Scene::settle_fast)
     int settled_oversub = 1;        // RTAMD_SETTLED_OVERSUB: grid of k_settled, in rounds of resident blocks
     int crown_nodes = 4096;         // RTAMD_CROWN_NODES: most inner nodes k_trace may keep in LDS (0: none); the LDS left beside the stacks bounds it too
+    int crown_min_blocks = 256;     // RTAMD_CROWN_MIN_BLOCKS: launches with fewer 256-ray tiles per queue shard (x 64 shards) walk without the crown
     int crown_partial = 0;          // RTAMD_CROWN_PARTIAL: 1 = keep the top of a tree that does not fit as a whole (measured: no gain)
 };
 

@@ -1366,7 +1366,9 @@ hipError_t launch_trace(hipStream_t s, const Tuning& tn, const TraceCfg& cfg, co
     // A wave refills its free lanes from its own run of the queue, so a run of one tile gives it nothing to refill
     // from.  When few rays are queued, launch fewer blocks rather than shorter runs: at least min_run rays per wave.
     const int min_run = std::max(8, tn.trace_min_run);
-    if (trace_uses_crown(tn, cfg, scene)) {
+    // (launches of a few hundred thousand rays run a little faster in the small blocks: the crown has to be copied into
+    // every block before its first ray)
+    if (trace_uses_crown(tn, cfg, scene) && blocks_per_shard >= (uint32_t)tn.crown_min_blocks) {
         // Large blocks, so that one copy of the crown serves many waves: [crown][stacks][world rays]
         constexpr int TB = CROWN_BLOCK;
         const size_t smem = (size_t)(CROWN_INST_SLOTS + scene.crown_n * (scene.wide ? 32u : 16u)) * sizeof(uint32_t) +

@@ -577,6 +577,7 @@ def test_tree_nodes_kept_in_lds_change_no_bit(name, env, width, fits, monkeypatc
     for case in (dict(RTAMD_CROWN_NODES="0"), env):
         for k in ("RTAMD_CROWN_NODES", "RTAMD_CROWN_PARTIAL", "RTAMD_FLAT_MAX"):
             monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("RTAMD_CROWN_MIN_BLOCKS", "0")  # (small frames here: take the crown at any launch size)
         if "RTAMD_FLAT_MAX" in env:
             monkeypatch.setenv("RTAMD_FLAT_MAX", env["RTAMD_FLAT_MAX"])
         for k, v in case.items():
