@@ -53,6 +53,7 @@ WORKLOADS = {
 }
 MAX_DEPTH = 50
 PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak
+COMPUTE_UNITS = 256  # MI355X
 DEFAULT_WORKLOAD = "final_scene"
 # one frame each, outside the timed steps, when the default workload runs on one rank
 OTHER_CONFIGS = ("c1_random_world", "c2_textures", "c3_random_world", "c4_cornell", "c5_synth10m")
@@ -319,6 +320,14 @@ def pmc_profile(workload, kernel, width=0, spp=0):
             continue
         if "valu_busy" in doc and "lane_use" in doc and profiled_size_matches(doc, width, spp):
             best = {"valu_busy": doc["valu_busy"], "lane_use": doc["lane_use"], "source": f.name}
+            # The other unit a tree walk saturates: a vector load whose lanes read scattered places costs the compute
+            # unit one clock per active lane (scripts/ta_probe.hip: 0.99 lane-loads per CU clock at best, a quarter of the
+            # cost when the four lanes of a quad share an address).  Lanes per load instruction are not counted by any
+            # counter collected here; the lanes per VALU instruction stand in for them.
+            c = doc.get("counters", {})
+            if c.get("SQ_INSTS_VMEM_RD") and doc.get("kernel_ms") and doc.get("clock_GHz"):
+                cu_clocks = doc["kernel_ms"] * 1e-3 * doc["clock_GHz"] * 1e9 * COMPUTE_UNITS
+                best["vmem_lane_loads_per_cu_clk"] = round(c["SQ_INSTS_VMEM_RD"] * 64.0 * doc["lane_use"] / cu_clocks, 3)
     return best
 
 
@@ -426,8 +435,9 @@ def kernel_rooflines(frames, stats, steps, workload, use_committed, width=0, spp
         roof["valu"] = valu
     if bound == "valu":
         roof["note"] = ("achieved/peak/frac are the kernel's algorithmic HBM bytes against the HBM peak; the kernel is bound by "
-                        "VALU instruction issue under divergence (valu: busy share of SIMD cycles, lanes active per instruction), "
-                        "not by memory")
+                        "VALU instruction issue under divergence (valu: busy share of SIMD cycles, lanes active per instruction) "
+                        "and, where valu.vmem_lane_loads_per_cu_clk is near 1, by the address cycles of its scattered loads (one "
+                        "compute-unit clock per active lane and load instruction), not by memory bandwidth")
     # the other kernels that take a real share of the step, in the same terms
     others = [one(*k) for k in ranked[1:] if k[1] > 0.15 * ranked[0][1] and k[3]]
     if others:
