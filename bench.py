@@ -246,7 +246,7 @@ ORACLE_FAST_FLAGS = ("-O3 -fno-semantic-interposition -ftls-model=initial-exec -
 def oracle_for_this_host():
     """(library path, flags) of the oracle build to time.  The committed fast build (oracle/liboracle_fast.so) targets a
     generic AVX2 server because it is compiled in one container and run on another host; when a compiler is at hand
-    the same source is rebuilt here with -march=native, as BASELINE.md describes the CPU baseline.  The rebuilt library
+    the same source is rebuilt here with -march=native (the CPU baseline is quoted for a build made for the host it runs on).  The rebuilt library
     must reproduce the checker build's image bit for bit on a small frame, else the committed one is used."""
     sys.path.insert(0, str(ROOT / "tests"))
     import shutil

@@ -108,7 +108,7 @@ struct rt_ctx {
     // -6 %, 10 M spheres -5 %, final_scene -0.6 %, cornell_smoke +1 %; same bits (a path's draws are keyed by pixel and sample).
     uint32_t slot_samples_log2 = 4;
     DevBuf d_state[2][5], d_hits, d_radiance, d_counts, d_rays, d_overflow, d_pixels, d_accum;  // ([4]: PathState::settled, split pipeline only)
-    // Knobs, all read from the environment once in rt_ctx_create (listed in INTEGRATION.md): launch shapes ...
+    // Knobs, all read from the environment once in rt_ctx_create: launch shapes ...
     rtk::Tuning tune;
     // ... and what rt_scene_commit / rt_render consult
     uint32_t flat_max = 48;      // RTAMD_FLAT_MAX: scenes of at most this many primitives are traced without a tree

@@ -29,6 +29,6 @@ for arg in sys.argv[1:]:
           f"settled {st.get('settled_ms', 0.0):7.2f} bounce {st['bounce_ms']:7.2f} tail {st['tail_ms']:5.2f} paths {st['paths_ms']:7.2f} | rays {st['rays']} settled {st['settled_rays']} | sum {acc.sum().item():.6e}", flush=True)
     if os.environ.get("VISITS") == "1":
         ctx.profile(events=False, count_visits=True)
-        _, sv = ctx.render(w, h, cam, 4, accum=acc)
+        _, sv = ctx.render(w, h, cam, int(os.environ.get("VISITS_SPP", "4")), accum=acc)
         print(f"               nodes/ray {sv['node_visits']/max(sv['rays'],1):.3f} prims/ray {sv['prim_tests']/max(sv['rays'],1):.3f} stack {ctx.info()['stack_entries']}", flush=True)
     ctx.close()
