@@ -66,13 +66,13 @@ struct Batch {
 struct Tuning {
     int oversub = 16;        // RTAMD_OVERSUB: grid of the per-bounce kernels, in rounds of resident blocks
     int trace_oversub = 2;   // RTAMD_TRACE_OVERSUB: the same for the persistent trace kernel
-    int stack_lds = 8;       // RTAMD_STACK_LDS: traversal-stack entries k_trace keeps in LDS per lane (deeper ones spill)
+    int stack_lds = 10;      // RTAMD_STACK_LDS: traversal-stack entries k_trace keeps in LDS per lane (deeper ones spill)
     int trace_min_run = 128; // RTAMD_TRACE_MIN_RUN (x8): fewest rays a wave of k_trace is given to refill from
     int refill = 24;         // RTAMD_REFILL: idle lanes at which a wave of k_trace fetches new rays
     int inner_steps = 4;     // RTAMD_INNER_STEPS: inner nodes per round of k_trace before the leaf step
     int regen = 8;           // RTAMD_REGEN: idle lanes at which a wave of k_paths starts new camera rays
     int paths_run = 1536;    // RTAMD_PATHS_RUN (x24): path slots per wave of k_paths
-    uint32_t settle_entry = 8;      // RTAMD_SETTLE_ENTRY: lanes of a wave that must qualify for its paths to be settled ahead
+    uint32_t settle_entry = 4;      // RTAMD_SETTLE_ENTRY: lanes of a wave that must qualify for its paths to be settled ahead
     uint32_t settle_near_hits = 1;  // RTAMD_SETTLE_NEAR_HITS: hits on the one primitive near a ball-shaped medium are settled too
     int settled_refill = 16;        // RTAMD_SETTLED_REFILL: idle lanes at which a wave of k_settled takes new paths
     int settled_min_run = 128;      // RTAMD_SETTLED_MIN_RUN: fewest paths a wave of k_settled is given
