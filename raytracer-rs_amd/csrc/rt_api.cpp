@@ -1681,10 +1681,10 @@ int rt_gather_frame(rt_ctx* c, uint32_t width, uint32_t height, uint32_t tile_si
     const uint64_t block = c->deal_block_pixels;  // every rank's share, padded to the largest
     if ((rc = ensure(c, c->d_gathered, (size_t)nranks * block * 3 * sizeof(float)))) return rc;
     float* gathered = (float*)c->d_gathered.p;
-    if (nranks == 1) {
+    if (nranks == 1 && !c->comm) {
         // one rank owns every tile: its packed block is the gathered buffer
         HIP_TRY(c, rtk::launch_pack_owned(c->stream, d, 0, d_in, gathered));
-    } else {
+    } else {  // (a communicator of one rank runs the collective all the same: the code N ranks run, on one GPU)
         if ((rc = ensure(c, c->d_packed, (size_t)block * 3 * sizeof(float)))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_packed.p, 0, (size_t)block * 3 * sizeof(float), c->stream));  // the padding of a smaller share
         HIP_TRY(c, rtk::launch_pack_owned(c->stream, d, rank, d_in, (float*)c->d_packed.p));

@@ -50,7 +50,8 @@ def test_gather_frame_single_rank_host_and_device(gpu_ctx):
 
 def test_communicator_of_one_rank_runs_the_collective_path():
     """rt_comm_unique_id + rt_comm_create load RCCL at run time and build a real communicator; with one rank the
-    gather is the identity, through the same code that N ranks run apart from the ncclAllGather call itself."""
+    gather is the identity, through the code that N ranks run, the ncclAllGather call on the communicator included
+    (host and device frames, two tile sizes, twice in a row)."""
     import torch
     ctx = rtamd.Context(0)
     try:
@@ -65,7 +66,11 @@ def test_communicator_of_one_rank_runs_the_collective_path():
     acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
     ctx.render(w, h, ctx.preset_camera(16 / 9), 2, seed=1, accum=acc)
     assert torch.equal(ctx.gather_frame(acc), acc)
+    assert torch.equal(ctx.gather_frame(acc, tile_size=8), acc)
+    host = acc.cpu().numpy()
+    assert np.array_equal(ctx.gather_frame(host), host)
     ctx.comm_destroy()
+    assert torch.equal(ctx.gather_frame(acc), acc)  # (and without a communicator again)
     with pytest.raises(rtamd.RtError):
         ctx.comm_create(uid, 3, 2)  # rank >= nranks
     ctx.close()
