@@ -1171,7 +1171,7 @@ int rt_scene_commit(rt_ctx* c, float shutter_t0, float shutter_t1) {
     {
         const uint32_t cap = rtk::crown_capacity(c->tune, ng > 0, wide, need);
         const bool worth = c->tune.crown_partial || n_nodes_total <= cap;  // (instances beyond CROWN_INST_SLOTS aside, it all fits)
-        if (!flat_ok && !nested && n_nodes_total > 0 && cap > 0 && worth &&
+        if (!flat_ok && !nested && n_nodes_total > 0 && n_nodes_total < rtd::CROWN_BASE && cap > 0 && worth &&
             (rc = build_crown(c, wide, top_r.root_ref, dgroups, cap, c->tune.crown_partial != 0, crown_words, crown_root)))
             return rc;
     }
