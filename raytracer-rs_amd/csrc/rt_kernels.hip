@@ -1335,13 +1335,16 @@ static hipError_t ensure_spill(SpillArea& spill, size_t need) {
 // Dynamic LDS beyond 64 KiB has to be asked for once per kernel.
 static hipError_t allow_lds(const void* fn, size_t smem) {
     static std::mutex mu;
-    static std::map<const void*, size_t> allowed;
+    static std::map<std::pair<const void*, int>, size_t> allowed;  // (kernel, device): the attribute belongs to the device's copy of the code
     if (smem <= 64u * 1024u) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = allowed.find(fn);
+    auto it = allowed.find(std::make_pair(fn, dev));
     if (it != allowed.end() && it->second >= smem) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess) allowed[fn] = smem;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) allowed[std::make_pair(fn, dev)] = smem;
     return e;
 }
 uint32_t crown_capacity(const Tuning& tn, bool has_groups, bool wide, uint32_t stack_cap) {
