@@ -12,6 +12,7 @@
 // No GPU is involved.
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -101,7 +102,7 @@ void idct_block(const int coef[64], const uint16_t q[64], uint8_t* out, int stri
             long tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
             z2 = in[0];
             z3 = in[4];
-            long tmp0 = (z2 + z3) << CB, tmp1 = (z2 - z3) << CB;
+            long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
             const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
             tmp0 = in[7];
             tmp1 = in[5];
@@ -173,7 +174,8 @@ int fail_msg(std::string* err, const char* msg) {
     return RT_ERR_UNSUPPORTED;
 }
 
-int decode_jpeg(const std::vector<uint8_t>& d, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgb, std::string* err) {
+// header_only: stops at the frame header (width and height known).
+int decode_jpeg(const std::vector<uint8_t>& d, bool header_only, uint32_t& width, uint32_t& height, std::vector<uint8_t>& rgb, std::string* err) {
     uint16_t qt[4][64];
     bool qt_present[4] = {false, false, false, false};
     Huff hdc[4], hac[4];
@@ -254,7 +256,10 @@ int decode_jpeg(const std::vector<uint8_t>& d, uint32_t& width, uint32_t& height
             for (int c = 1; c < nc; c++) chroma_ok = chroma_ok && comp[c].h == 1 && comp[c].v == 1;
             if (hmax > 2 || vmax > 2 || !luma_full || (nc == 3 && !chroma_ok) || (hmax == 1 && vmax == 2))
                 return fail_msg(err, "JPEG: chroma sampling other than 1x1, 2x1 or 2x2");
+            // (65535 x 65535 would be 12 GB of planes: a texture of more than 2^28 texels is refused, not attempted)
+            if ((uint64_t)width * height > (1ull << 28)) return fail_msg(err, "JPEG: more than 2^28 pixels");
             have_frame = true;
+            if (header_only) return RT_OK;
         } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
             return fail_msg(err, "JPEG: only baseline Huffman files (this one is progressive, lossless or arithmetic-coded)");
         } else if (m == 0xDD) {
@@ -396,17 +401,20 @@ bool read_file(const char* path, std::vector<uint8_t>& out) {
 
 }  // namespace
 
-extern "C" {
-
-int rt_image_read(const char* path, uint32_t* width, uint32_t* height, uint8_t* rgb, uint64_t cap_bytes) {
-    if (!path || !width || !height) return RT_ERR_INVALID;
+namespace {
+int image_read(const char* path, uint32_t* width, uint32_t* height, uint8_t* rgb, uint64_t cap_bytes) {
     std::vector<uint8_t> d;
     if (!read_file(path, d)) return RT_ERR_IO;
     std::vector<uint8_t> pix;
     uint32_t w = 0, h = 0;
     if (d.size() >= 4 && d[0] == 0xFF && d[1] == 0xD8) {
-        const int rc = decode_jpeg(d, w, h, pix, nullptr);
+        const int rc = decode_jpeg(d, rgb == nullptr, w, h, pix, nullptr);
         if (rc) return rc;
+        if (!rgb) {
+            *width = w;
+            *height = h;
+            return RT_OK;
+        }
     } else if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') {
         // "P6" width height maxval, separated by white space (comments start with #), one white-space byte, then the rows
         size_t at = 2;
@@ -438,6 +446,18 @@ int rt_image_read(const char* path, uint32_t* width, uint32_t* height, uint8_t* 
         memcpy(rgb, pix.data(), pix.size());
     }
     return RT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_image_read(const char* path, uint32_t* width, uint32_t* height, uint8_t* rgb, uint64_t cap_bytes) {
+    if (!path || !width || !height) return RT_ERR_INVALID;
+    try {
+        return image_read(path, width, height, rgb, cap_bytes);
+    } catch (const std::exception&) {  // (no memory for what the file's header claims): nothing is thrown across the boundary
+        return RT_ERR_UNSUPPORTED;
+    }
 }
 
 }  // extern "C"

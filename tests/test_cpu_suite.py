@@ -406,6 +406,14 @@ def test_image_read_errors_and_ppm(tmp_path):
     (tmp_path / "cut2.jpg").write_bytes(raw[:scan - 20])
     with pytest.raises(rtamd.RtError):
         rtamd.read_image(tmp_path / "cut2.jpg")
+    # a frame header that claims 65535 x 65535 pixels is refused at the header, not attempted (12 GB of planes)
+    sof = raw.index(b"\xff\xc0")
+    huge = bytearray(raw)
+    huge[sof + 5:sof + 9] = b"\xff\xff\xff\xff"
+    (tmp_path / "huge.jpg").write_bytes(bytes(huge))
+    with pytest.raises(rtamd.RtError) as e:
+        rtamd.read_image(tmp_path / "huge.jpg")
+    assert e.value.code == -3
 
 
 def test_mirror_image_texture_reads_a_jpeg(tmp_path):
