@@ -465,9 +465,17 @@ def other_configs(device, n_synth):
             f.render(spp=spp if n_paths <= (1 << 31) else 1, exchange=False)  # allocations, kernel loading
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            st.append(f.render(exchange=False))
+            last = f.render(exchange=False)
             torch.cuda.synchronize()
-            dt += time.perf_counter() - t0
+            one = time.perf_counter() - t0
+            if one < 0.1:  # a frame of a few milliseconds: the mean of ten renders instead of one sample
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    last = f.render(exchange=False)
+                torch.cuda.synchronize()
+                one = (time.perf_counter() - t0) / 10
+            st.append(last)
+            dt += one
             frames.append(f)
         roof = kernel_rooflines(frames, [st], 1, wl, use_committed=True)
         rays = sum(s["rays"] for s in st)
